@@ -1,0 +1,166 @@
+/*
+ * rt_amd.h — C-ABI of the MI355X ray-tracing hot path.
+ *
+ * The reference (Wei-Parker-Guo/RayTracer) has no FFI layer; its renderer is
+ * reached through three C++ seams.  Each entry point below replaces one of
+ * them and cites it.  Everything crosses the boundary as plain pointers and
+ * sizes; handles are opaque; every call returns an int status (RT_OK == 0)
+ * and never throws.  The caller owns all input arrays (they are copied
+ * during the call) and every output buffer; the library owns device memory
+ * until rt_scene_destroy.
+ *
+ * Pointer arguments documented as "host or device" are classified with
+ * hipPointerGetAttributes: device pointers are used in place, host pointers
+ * are staged through a device buffer and copied on the given stream.
+ *
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ * All work of a call is enqueued on that stream; calls that write to host
+ * memory synchronise the stream before returning.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,     /* bad argument (null, negative size, rect outside the image ...) */
+    RT_ERR_HIP = 2,         /* a HIP runtime call failed; see rt_last_error */
+    RT_ERR_NO_DEVICE = 3,   /* no gfx950 device visible */
+    RT_ERR_UNSUPPORTED = 4  /* e.g. more lights than RT_MAX_LIGHTS */
+};
+
+enum { RT_MAT_DEFAULT = 0, RT_MAT_LAMBERT = 1, RT_MAT_PHONG = 2, RT_MAT_REFRAC = 3 };
+enum { RT_LIGHT_DIRECTIONAL = 0, RT_LIGHT_POINT = 1 };
+enum { RT_JITTER_OFF = 0, RT_JITTER_HASH = 1 };
+enum { RT_MAX_LIGHTS = 8 };
+
+/* One mesh = what Mesh::construct_unit_surfaces produces (reference
+ * src/geometry.cpp:360-376): triangles in face order, world space, with the
+ * three vertex normals.  pos/nrm are [n_tris][3][3] floats (host memory).
+ * name must be unique in the scene and at most 31 bytes (src/geometry.h:108). */
+typedef struct rt_mesh_desc {
+    char name[32];
+    int32_t material;       /* index into the materials array */
+    int32_t n_tris;
+    const float* pos;
+    const float* nrm;
+} rt_mesh_desc;
+
+/* Material parameters as the reference's Lambert/Phong/Refrac constructors
+ * read them (src/materials.cpp:10-21,45-66,90-118).  64 bytes. */
+typedef struct rt_material_desc {
+    int32_t kind;           /* RT_MAT_* */
+    float base[3];
+    float ambient[3];
+    float spec[3];
+    float transp[3];
+    float shininess;
+    float reflectivity;
+    float refractivity;
+} rt_material_desc;
+
+/* src/lights.cpp:7-25.  Directional: vec = unit vector toward the light
+ * (already negated as src/main.cpp:369 does).  Point: vec = position.  32 bytes. */
+typedef struct rt_light_desc {
+    int32_t kind;           /* RT_LIGHT_* */
+    float vec[3];
+    float color[3];
+    float pad_;
+} rt_light_desc;
+
+/* src/cameras.cpp:3-18: w is Camera::lookat, i.e. the BACKWARD unit vector.  64 bytes. */
+typedef struct rt_camera_desc {
+    float pos[3];
+    float up[3];
+    float w[3];
+    float side[3];
+    float near_clip;
+    float far_clip;
+    float pad_[2];
+} rt_camera_desc;
+
+/* The argument list of RenderThread::operator() (src/render_thread.h:22-25)
+ * plus the image size the Rasterizer carries, and the knobs this build adds. */
+typedef struct rt_options {
+    int32_t width, height;      /* -dispw / -disph */
+    float hfov;                 /* -hfov, degrees */
+    int32_t spp;                /* -spp n: n x n samples per pixel */
+    int32_t spr;                /* -spr n: n jittered + 1 exact ray per split */
+    int32_t max_bounce;         /* -bounce */
+    int32_t max_refrac_bounce;  /* -rbounce */
+    float eps;                  /* -eps */
+    float ray_eps;              /* -reps */
+    int32_t jitter_mode;        /* RT_JITTER_OFF: every rand() is 100 (no jitter);
+                                   RT_JITTER_HASH: counter hash keyed by (seed, pixel, sample, ray path, call site) */
+    uint32_t seed;
+    int32_t exact_boxes;        /* 1: slab test with IEEE division and no nearest-hit pruning — visits exactly
+                                      the triangles the reference visits; 0: reciprocal multiply + pruning */
+    int32_t reserved_[4];
+} rt_options;
+
+typedef struct rt_stats {
+    uint64_t rays_closest;      /* nearest-hit queries traced (primary + secondary render rays) */
+    uint64_t rays_any;          /* any-hit queries traced (light-visibility rays) */
+    uint64_t ref_get_hit_calls; /* get_hit calls the reference would make for the same work
+                                   (it traces every render ray twice, src/render_thread.cpp:82-104,269-280) */
+    uint64_t nodes_visited;     /* only with exact_boxes... filled by rt_trace_counted */
+    uint64_t tris_tested;
+    float ms_total;             /* device time of the whole call (HIP events on the call's stream) */
+    float ms_extend;            /* nearest-hit kernels */
+    float ms_shadow;            /* any-hit kernels */
+    float ms_shade;             /* shade / spawn / resolve kernels */
+    int32_t levels;             /* bounce levels processed */
+    int32_t reserved_[3];
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+/* Library/device bring-up.  device < 0 keeps the current HIP device. */
+int rt_init(int device);
+
+/* Text of the last error on the calling thread. */
+const char* rt_last_error(void);
+
+/* Replaces AABBTree::AABBTree(std::vector<Mesh*>&) (src/AABBTree.cpp:3-16) together with
+ * BVHNode::BVHNode(std::vector<Surface*>, int, int) (src/geometry.cpp:61-153): builds the same
+ * midpoint-partition tree per mesh on the host, flattens it and uploads it to the current device. */
+int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes,
+                    const rt_material_desc* materials, int n_materials,
+                    const rt_light_desc* lights, int n_lights,
+                    const rt_camera_desc* camera, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+
+/* Shape of the flattened tree: counts[0]=triangles, [1]=inner nodes, [2]=leaves, [3]=max depth. */
+int rt_scene_info(const rt_scene* scene, int64_t counts[4]);
+
+/* Replaces bool get_hit(const AABBTree&, const Ray*, float t0, float t1, hitrec&)
+ * (src/render_thread.h:17, src/render_thread.cpp:5-23) in batch form.
+ * org/dir: [n][3] floats, host or device.  t_out[n] = hit distance or +inf; tri_out[n] = global
+ * triangle id (mesh order, then face order) or -1; nrm_out[n][3] = interpolated unit normal
+ * (may be NULL).  any_hit != 0 answers only "is there a hit" (what src/render_thread.cpp:158 uses):
+ * t_out is then 0 (occluded) or +inf and tri_out is 0/-1. */
+int rt_trace(rt_scene* scene, const float* org, const float* dir, float t0, float t1, int64_t n,
+             int any_hit, int exact_boxes, float* t_out, int32_t* tri_out, float* nrm_out, void* stream);
+
+/* Replaces RenderThread::operator()(Rasterizer*, AABBTree&, Camera*, std::vector<Light*>, int startX,
+ * int startY, int endX, int endY, ...) (src/render_thread.h:22-25, src/render_thread.cpp:25-488).
+ * Renders pixels x in [x0,x1), y in [y0,y1) (y = 0 is the bottom row, as in the reference) and writes
+ * float RGB = sum(colours)/sum(weights) per pixel (src/rasterizer.cpp:88-103; no draw -> NaN) into
+ * rgb_out[(y - y0) * (x1 - x0) + (x - x0)][3], host or device.  stats may be NULL. */
+int rt_render_rect(rt_scene* scene, const rt_options* opt, int x0, int y0, int x1, int y1,
+                   float* rgb_out, rt_stats* stats, void* stream);
+
+/* Replaces the 8-bit conversion of save_jpg (src/main.cpp:157-167):
+ * out[(H-1-y)*W + x][c] = max(0, min(255, (int)floor(rgb * 256.0))), NaN -> 0.  rgb is [H][W][3] with row 0
+ * at the bottom; out is top-down.  Both host or device. */
+int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */
