@@ -100,7 +100,9 @@ typedef struct rt_options {
     uint32_t seed;
     int32_t exact_boxes;        /* 1: slab test with IEEE division and no nearest-hit pruning — visits exactly
                                       the triangles the reference visits; 0: reciprocal multiply + pruning */
-    int32_t reserved_[4];
+    int32_t count_traversal;    /* 1: also count inner nodes fetched and triangles tested per kernel kind into
+                                   rt_stats (slower kernels; for traffic accounting, not for timing) */
+    int32_t reserved_[3];
 } rt_options;
 
 typedef struct rt_stats {
@@ -108,8 +110,10 @@ typedef struct rt_stats {
     uint64_t rays_any;          /* any-hit queries traced (light-visibility rays) */
     uint64_t ref_get_hit_calls; /* get_hit calls the reference would make for the same work
                                    (it traces every render ray twice, src/render_thread.cpp:82-104,269-280) */
-    uint64_t nodes_visited;     /* only with exact_boxes... filled by rt_trace_counted */
-    uint64_t tris_tested;
+    uint64_t nodes_extend;      /* with count_traversal: 64-byte inner nodes fetched by the nearest-hit kernels */
+    uint64_t tris_extend;       /*                       48-byte triangles tested by them */
+    uint64_t nodes_shadow;      /* the same for the any-hit kernels */
+    uint64_t tris_shadow;
     float ms_total;             /* device time of the whole call (HIP events on the call's stream) */
     float ms_extend;            /* nearest-hit kernels */
     float ms_shadow;            /* any-hit kernels */
@@ -146,6 +150,12 @@ int rt_scene_info(const rt_scene* scene, int64_t counts[4]);
  * t_out is then 0 (occluded) or +inf and tri_out is 0/-1. */
 int rt_trace(rt_scene* scene, const float* org, const float* dir, float t0, float t1, int64_t n,
              int any_hit, int exact_boxes, float* t_out, int32_t* tri_out, float* nrm_out, void* stream);
+
+/* rt_trace plus, per ray, the number of inner nodes fetched and triangles tested (for traffic accounting).
+ * No counterpart in the reference. */
+int rt_trace_counted(rt_scene* scene, const float* org, const float* dir, float t0, float t1, int64_t n,
+                     int any_hit, int exact_boxes, float* t_out, int32_t* tri_out,
+                     uint32_t* nodes_out, uint32_t* tris_out, void* stream);
 
 /* Replaces RenderThread::operator()(Rasterizer*, AABBTree&, Camera*, std::vector<Light*>, int startX,
  * int startY, int endX, int endY, ...) (src/render_thread.h:22-25, src/render_thread.cpp:25-488).

@@ -10,8 +10,8 @@
 // the reference itself.  It is checked against analytic known answers (tests/test_oracle.py).
 //
 // Defined where the reference is undefined (uninitialised reads):
-//   * reflect children inherit the parent's weight and get refraci = 1
-//     (src/render_thread.cpp:240-262 never set them);
+//   * reflect children inherit the parent's weight and refraci (src/render_thread.cpp:240-262 never set
+//     them; inheriting refraci also keeps the ray tree finite: only a ray with refraci == 1 resets depth, :322-336);
 //   * refract/reflect children of a refractive hit get total_previous_contrib = 0
 //     (src/render_thread.cpp:319-337);
 //   * a TriangleSet's box is the union of its triangles' boxes (src/geometry.cpp:413-417 starts the
@@ -445,7 +445,7 @@ void render_pixel(const orc_scene& sc, const rt_options& o, int i, int j, float 
                     reflect(ray.g, rec.norm, rec.t, rr.g);
                     v_copy(rr.c_cache, ray.c_cache);
                     rr.contrib = ray.contrib; rr.tpc = ray.tpc;
-                    rr.weight = ray.weight; rr.refraci = 1;                         // defined (header)
+                    rr.weight = ray.weight; rr.refraci = ray.refraci;               // defined (header)
                     std::vector<Ray> subs;
                     for (int k = 0; k < spr; ++k) {
                         Ray s = rr;

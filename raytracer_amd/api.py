@@ -1,0 +1,130 @@
+"""Host-side mirror of the reference's renderer seams over the C-ABI of librt_amd.so.
+
+    TracerScene(scene)                  <- AABBTree::AABBTree          (reference src/AABBTree.cpp:3-16)
+    TracerScene.trace(org, dir, t0, t1) <- get_hit                     (src/render_thread.cpp:5-23)
+    TracerScene.render_rect(opt, rect)  <- RenderThread::operator()    (src/render_thread.cpp:25-488)
+    resolve_u8(rgb)                     <- save_jpg's 8-bit conversion (src/main.cpp:157-167)
+
+There is no CPU fallback: importing works without a GPU (so that symbols can be checked), every compute call needs
+the HIP library and a gfx950 device and raises otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import CameraDesc, LightDesc, MaterialDesc, MeshDesc, Options, Stats, pack_scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+_LIB = None
+
+EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_trace",
+           "rt_trace_counted", "rt_render_rect", "rt_resolve_u8"]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads librt_amd.so (built by raytracer_amd/csrc/Makefile); raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError("%s is missing: build it with `make -C raytracer_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i64, f32 = C.c_void_p, C.c_int64, C.c_float
+        L.rt_init.argtypes = [C.c_int]
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_scene_create.argtypes = [C.POINTER(MeshDesc), C.c_int, C.POINTER(MaterialDesc), C.c_int,
+                                      C.POINTER(LightDesc), C.c_int, C.POINTER(CameraDesc), C.POINTER(vp)]
+        L.rt_scene_destroy.argtypes = [vp]
+        L.rt_scene_info.argtypes = [vp, C.POINTER(i64)]
+        L.rt_trace.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.rt_trace_counted.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.rt_render_rect.argtypes = [vp, C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                     C.POINTER(Stats), vp]
+        L.rt_resolve_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtError("%s failed (%d): %s" % (what, rc, lib().rt_last_error().decode()))
+
+
+def init(device=-1):
+    _check(lib().rt_init(device), "rt_init")
+
+
+def _ptr(a):
+    """Address of a numpy array or of a torch tensor (host or device)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+class TracerScene:
+    """A scene resident on the current device: flattened tree, triangles, materials, lights, camera."""
+
+    def __init__(self, scene):
+        meshes, mats, lights, cam, keep = pack_scene(scene)
+        h = C.c_void_p()
+        _check(lib().rt_scene_create(meshes, len(scene.meshes), mats, len(scene.materials), lights,
+                                     len(scene.lights), C.byref(cam), C.byref(h)), "rt_scene_create")
+        self._h = h
+        self.scene = scene
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def info(self):
+        c = (C.c_int64 * 4)()
+        _check(lib().rt_scene_info(self._h, c), "rt_scene_info")
+        return dict(tris=c[0], inner=c[1], leaves=c[2], depth=c[3])
+
+    def trace(self, org, dir, t0, t1, any_hit=False, exact_boxes=False, counted=False, stream=None):
+        """Nearest (or any) hit of n rays.  numpy in -> numpy out (t, tri, normal[, nodes, tris])."""
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1, 3)
+        n = org.shape[0]
+        t = np.empty(n, np.float32)
+        tri = np.empty(n, np.int32)
+        if counted:
+            cn = np.empty(n, np.uint32)
+            ct = np.empty(n, np.uint32)
+            _check(lib().rt_trace_counted(self._h, _ptr(org), _ptr(dir), t0, t1, n, int(any_hit), int(exact_boxes),
+                                          _ptr(t), _ptr(tri), _ptr(cn), _ptr(ct), stream), "rt_trace_counted")
+            return t, tri, cn, ct
+        nrm = np.empty((n, 3), np.float32)
+        _check(lib().rt_trace(self._h, _ptr(org), _ptr(dir), t0, t1, n, int(any_hit), int(exact_boxes),
+                              _ptr(t), _ptr(tri), _ptr(nrm), stream), "rt_trace")
+        return t, tri, nrm
+
+    def render_rect(self, opt, x0, y0, x1, y1, out=None, stats=True, stream=None):
+        """Renders the pixel rectangle; `out` may be a numpy array or a CUDA torch tensor [y1-y0, x1-x0, 3] float32
+        (device tensors are written in place, asynchronously on `stream`)."""
+        if out is None:
+            out = np.empty((y1 - y0, x1 - x0, 3), np.float32)
+        st = Stats() if stats else None
+        _check(lib().rt_render_rect(self._h, C.byref(opt), x0, y0, x1, y1, _ptr(out),
+                                    C.byref(st) if st is not None else None, stream), "rt_render_rect")
+        return out, st
+
+
+def resolve_u8(rgb, out=None, stream=None):
+    """[H, W, 3] float32 (row 0 = bottom) -> [H, W, 3] uint8 (row 0 = top)."""
+    h, w = rgb.shape[0], rgb.shape[1]
+    if out is None:
+        out = np.empty((h, w, 3), np.uint8)
+    _check(lib().rt_resolve_u8(_ptr(rgb), w, h, _ptr(out), stream), "rt_resolve_u8")
+    return out

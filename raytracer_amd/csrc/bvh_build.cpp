@@ -1,0 +1,184 @@
+// Host-side tree build + flattening.
+//
+// Builds, per mesh, the same midpoint-partition tree as the reference's
+// BVHNode::BVHNode(std::vector<Surface*>, int AXIS, int depth) (src/geometry.cpp:61-153, called from
+// src/AABBTree.cpp:10 with AXIS 0 and depth 64) and writes it straight into the flat device layout
+// (rt_types.h).  Differences in representation, not in the set of boxes and triangle groups:
+//   * a node's box is stored in its parent (both children's boxes in one 64-byte record);
+//   * the bottom nodes of the reference (a node holding one triangle, two triangles, or a TriangleSet)
+//     become leaves: a run of consecutive triangles plus the box the reference tests before them;
+//   * triangles are emitted in "tie order": wherever the reference prefers one candidate on equal t
+//     (right child over left, src/geometry.cpp:171-175; lower index inside a set, :428; earlier mesh,
+//     src/render_thread.cpp:15) that candidate gets the lower position, so "lowest position wins ties"
+//     reproduces its choice under any traversal order;
+//   * the meshes' roots hang under a small top tree over mesh boxes instead of being looped over
+//     (src/render_thread.cpp:10); a parent box is the exact union of its children, so it never fails
+//     where a descendant passes.
+// Where the reference reads uninitialised memory (TriangleSet box seed, src/geometry.cpp:413; box of a
+// depth-capped node, :65-69) the union of the triangles' boxes is used.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace rt {
+namespace {
+
+struct Box { float lo[3], hi[3]; };
+
+inline void box_union(Box& a, const Box& b) {                 // src/geometry.cpp:3-12
+    for (int i = 0; i < 3; ++i) { a.lo[i] = fminf(a.lo[i], b.lo[i]); a.hi[i] = fmaxf(a.hi[i], b.hi[i]); }
+}
+
+struct Built { int32_t ref; Box box; int depth; };
+
+struct Builder {
+    const float* pos;      // current mesh: [n][3][3]
+    const float* nrm;
+    int mesh_index;
+    int id_base;           // global id of the mesh's first triangle
+    std::vector<Box> tbox; // per triangle of the current mesh
+    FlatScene* out;
+
+    Box tri_box(int k) const {                                  // src/geometry.cpp:314-321
+        const float* a = pos + (size_t)k * 9; const float* b = a + 3; const float* c = a + 6;
+        Box r;
+        for (int i = 0; i < 3; ++i) {
+            r.lo[i] = fminf(a[i], fminf(b[i], c[i]));
+            r.hi[i] = fmaxf(a[i], fmaxf(b[i], c[i]));
+        }
+        return r;
+    }
+
+    Built leaf(const int* ids, int n) {
+        Built r; r.depth = 0;
+        r.ref = ~(int32_t)out->tris.size();
+        r.box = tbox[ids[0]];
+        for (int k = 0; k < n; ++k) {
+            const int t = ids[k];
+            box_union(r.box, tbox[t]);
+            const float* a = pos + (size_t)t * 9; const float* b = a + 3; const float* c = a + 6;
+            Tri48 q;
+            q.ax = a[0]; q.ay = a[1]; q.az = a[2]; q.run = n - k;
+            q.abx = a[0] - b[0]; q.aby = a[1] - b[1]; q.abz = a[2] - b[2]; q.id = id_base + t;
+            q.acx = a[0] - c[0]; q.acy = a[1] - c[1]; q.acz = a[2] - c[2]; q.mesh = mesh_index;
+            out->tris.push_back(q);
+            const float* nn = nrm + (size_t)t * 9;
+            out->nrm.insert(out->nrm.end(), nn, nn + 9);
+        }
+        out->n_leaves++;
+        return r;
+    }
+
+    Built build(const std::vector<int>& s, int axis, int depth) {
+        const int N = (int)s.size();
+        if (depth == 0 || N == 1) return leaf(s.data(), N);
+        if (N == 2) { const int sw[2] = {s[1], s[0]}; return leaf(sw, 2); }   // the right one wins ties
+        Box sb = tbox[s[0]];
+        for (int t : s) box_union(sb, tbox[t]);
+        const float m = sb.lo[axis] + (sb.hi[axis] - sb.lo[axis]) / 2;        // :97, midpoint on the incoming axis
+        int div_dif = std::numeric_limits<int>::max(), best_axis = 0;
+        for (int a = 0; a < 3; ++a) {                                          // :104-121, the same m for every axis
+            int nl = 0;
+            for (int t : s) {
+                const Box& b = tbox[t];
+                const float bm = b.lo[axis] + (b.hi[axis] - b.lo[axis]) / 2;
+                if (bm < m) ++nl;
+            }
+            const int d = std::abs(nl - (N - nl));
+            if (d < div_dif) { div_dif = d; best_axis = axis; }
+            axis = (axis + 1) % 3;
+        }
+        axis = best_axis;
+        std::vector<int> ll, rl;
+        for (int t : s) {
+            const Box& b = tbox[t];
+            const float bm = b.lo[axis] + (b.hi[axis] - b.lo[axis]) / 2;
+            if (bm < m) ll.push_back(t); else rl.push_back(t);
+        }
+        if (ll.empty()) return leaf(rl.data(), N);                             // :135-139
+        if (rl.empty()) return leaf(ll.data(), N);                             // :142-146
+        const int32_t idx = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        const Built R = build(rl, (axis + 1) % 3, depth - 1);                  // right first: lower tie positions
+        const Built L = build(ll, (axis + 1) % 3, depth - 1);
+        Node64& n = out->nodes[idx];
+        memcpy(n.lbox, L.box.lo, 12); memcpy(n.lbox + 3, L.box.hi, 12);
+        memcpy(n.rbox, R.box.lo, 12); memcpy(n.rbox + 3, R.box.hi, 12);
+        n.lref = L.ref; n.rref = R.ref; n.pad[0] = n.pad[1] = 0;
+        Built r; r.ref = idx; r.box = L.box; box_union(r.box, R.box);
+        r.depth = 1 + std::max(L.depth, R.depth);
+        return r;
+    }
+};
+
+// Top tree over mesh roots: median split of box centres along the widest axis.
+Built build_top(FlatScene* out, std::vector<Built>& roots, int lo, int hi) {
+    if (hi - lo == 1) return roots[lo];
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = lo; k < hi; ++k)
+        for (int i = 0; i < 3; ++i) {
+            const float c = 0.5f * (roots[k].box.lo[i] + roots[k].box.hi[i]);
+            cmin[i] = fminf(cmin[i], c); cmax[i] = fmaxf(cmax[i], c);
+        }
+    int ax = 0;
+    for (int i = 1; i < 3; ++i) if (cmax[i] - cmin[i] > cmax[ax] - cmin[ax]) ax = i;
+    const int mid = (lo + hi) / 2;
+    std::nth_element(roots.begin() + lo, roots.begin() + mid, roots.begin() + hi, [ax](const Built& a, const Built& b) {
+        return a.box.lo[ax] + a.box.hi[ax] < b.box.lo[ax] + b.box.hi[ax];
+    });
+    const int32_t idx = (int32_t)out->nodes.size();
+    out->nodes.emplace_back();
+    const Built L = build_top(out, roots, lo, mid);
+    const Built R = build_top(out, roots, mid, hi);
+    Node64& n = out->nodes[idx];
+    memcpy(n.lbox, L.box.lo, 12); memcpy(n.lbox + 3, L.box.hi, 12);
+    memcpy(n.rbox, R.box.lo, 12); memcpy(n.rbox + 3, R.box.hi, 12);
+    n.lref = L.ref; n.rref = R.ref; n.pad[0] = n.pad[1] = 0;
+    Built r; r.ref = idx; r.box = L.box; box_union(r.box, R.box);
+    r.depth = 1 + std::max(L.depth, R.depth);
+    return r;
+}
+
+}  // namespace
+
+bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, std::string* err) {
+    out->nodes.clear(); out->tris.clear(); out->nrm.clear();
+    out->n_leaves = 0; out->max_depth = 0;
+    out->nodes.emplace_back();                       // node 0 = entry, filled in last
+    std::vector<Built> roots;
+    int id_base = 0;
+    for (int mi = 0; mi < n_meshes; ++mi) {
+        const rt_mesh_desc& md = meshes[mi];
+        if (md.n_tris < 0 || (md.n_tris > 0 && (!md.pos || !md.nrm))) { *err = "mesh with null arrays or negative size"; return false; }
+        if (md.n_tris == 0) continue;
+        Builder b;
+        b.pos = md.pos; b.nrm = md.nrm; b.mesh_index = mi; b.id_base = id_base; b.out = out;
+        b.tbox.resize(md.n_tris);
+        std::vector<int> ids(md.n_tris);
+        for (int k = 0; k < md.n_tris; ++k) { b.tbox[k] = b.tri_box(k); ids[k] = k; }
+        roots.push_back(b.build(ids, 0, 64));         // src/AABBTree.cpp:10
+        id_base += md.n_tris;
+    }
+    if (roots.empty()) { *err = "scene has no triangles"; return false; }
+    Node64 entry;
+    memset(&entry, 0, sizeof(entry));
+    int depth;
+    if (roots.size() == 1) {
+        memcpy(entry.lbox, roots[0].box.lo, 12); memcpy(entry.lbox + 3, roots[0].box.hi, 12);
+        entry.lref = roots[0].ref; entry.rref = RT_NONE;
+        depth = 1 + roots[0].depth;
+    } else {
+        const Built top = build_top(out, roots, 0, (int)roots.size());
+        entry = out->nodes[top.ref];                  // copy the top node into slot 0 (its own slot stays unused)
+        depth = top.depth;
+    }
+    out->nodes[0] = entry;
+    out->max_depth = depth;
+    return true;
+}
+
+}  // namespace rt

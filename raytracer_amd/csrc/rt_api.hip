@@ -1,0 +1,398 @@
+// C-ABI of the library (declared and documented in include/rt_amd.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "bvh_build.h"
+#include "rt_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+struct LevelBuf {
+    rt::Level L{};
+    int64_t cap = 0;
+    int lights = 0;
+};
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    rt::DScene d{};
+    int64_t n_tris = 0, n_inner = 0, n_leaves = 0, max_depth = 0;
+    int n_lights = 0;
+    bool any_spawning_material = false;
+    std::vector<void*> owned;
+    // render workspace, grown on demand; one render at a time per scene
+    std::mutex mu;
+    LevelBuf lv[rt::RT_MAX_LEVELS];
+    uint32_t* d_counters = nullptr;          // [0] children of the level, [1] spawn cursor, [2..3] light rays (u64),
+                                             // [4..7] extend nodes/tris (2 x u64), [8..11] shadow nodes/tris
+    uint32_t* h_counters = nullptr;          // pinned mirror
+    float* d_stage = nullptr; int64_t stage_cap = 0;
+    void* d_io = nullptr; int64_t io_cap = 0;  // staging for rt_trace / rt_resolve_u8 host buffers
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+template <class T>
+int upload(rt_scene* sc, const T* src, size_t n, const T** dst) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    sc->owned.push_back(p);
+    if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+void free_level(LevelBuf& b) {
+    if (b.L.org) (void)hipFree(b.L.org);
+    if (b.L.dir) (void)hipFree(b.L.dir);
+    if (b.L.meta) (void)hipFree(b.L.meta);
+    if (b.L.hit) (void)hipFree(b.L.hit);
+    if (b.L.tri) (void)hipFree(b.L.tri);
+    if (b.L.kids) (void)hipFree(b.L.kids);
+    if (b.L.aux) (void)hipFree(b.L.aux);
+    if (b.L.unocc) (void)hipFree(b.L.unocc);
+    b = LevelBuf();
+}
+
+int ensure_level(LevelBuf& b, int64_t n, int lights) {
+    lights = std::max(lights, 1);
+    if (b.cap >= n && b.lights >= lights) return RT_OK;
+    const int64_t cap = std::max<int64_t>(n + n / 4, 1024);
+    free_level(b);
+    HIP_TRY(hipMalloc((void**)&b.L.org, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&b.L.dir, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&b.L.meta, cap * sizeof(int4)));
+    HIP_TRY(hipMalloc((void**)&b.L.hit, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&b.L.tri, cap * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&b.L.kids, cap * sizeof(int2)));
+    HIP_TRY(hipMalloc((void**)&b.L.aux, cap * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&b.L.unocc, cap * lights * sizeof(uint32_t)));
+    b.cap = cap; b.lights = lights;
+    return RT_OK;
+}
+
+int ensure_bytes(void** p, int64_t* cap, int64_t need) {
+    if (*cap >= need) return RT_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(p, (size_t)need));
+    *cap = need;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device >= 0) {
+        if (device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+    }
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cur));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_desc* materials, int n_materials,
+                    const rt_light_desc* lights, int n_lights, const rt_camera_desc* camera, rt_scene** out) {
+    if (!meshes || n_meshes <= 0 || !materials || n_materials <= 0 || !camera || !out || n_lights < 0 || (n_lights > 0 && !lights))
+        return fail(RT_ERR_INVALID, "rt_scene_create: null or empty argument");
+    if (n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_UNSUPPORTED, "more lights than RT_MAX_LIGHTS");
+    for (int i = 0; i < n_meshes; ++i) {
+        if (meshes[i].material < 0 || meshes[i].material >= n_materials) return fail(RT_ERR_INVALID, "mesh material index out of range");
+        for (int j = 0; j < i; ++j)
+            if (strncmp(meshes[i].name, meshes[j].name, 32) == 0) return fail(RT_ERR_INVALID, "mesh names must be unique");
+    }
+    rt::FlatScene flat;
+    std::string err;
+    if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
+    if (flat.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+
+    rt_scene* sc = new rt_scene();
+    (void)hipGetDevice(&sc->device);
+    int rc;
+    std::vector<rt::Material> mats(n_materials);
+    for (int i = 0; i < n_materials; ++i) {
+        static_assert(sizeof(rt::Material) == sizeof(rt_material_desc), "material layouts must match");
+        memcpy(&mats[i], &materials[i], sizeof(rt::Material));
+        if (materials[i].kind == RT_MAT_PHONG || materials[i].kind == RT_MAT_REFRAC) sc->any_spawning_material = true;
+    }
+    std::vector<int32_t> mesh_mat(n_meshes);
+    for (int i = 0; i < n_meshes; ++i) mesh_mat[i] = meshes[i].material;
+    if ((rc = upload(sc, flat.nodes.data(), flat.nodes.size(), &sc->d.nodes)) != RT_OK ||
+        (rc = upload(sc, flat.tris.data(), flat.tris.size(), &sc->d.tris)) != RT_OK ||
+        (rc = upload(sc, flat.nrm.data(), flat.nrm.size(), &sc->d.nrm)) != RT_OK ||
+        (rc = upload(sc, mats.data(), mats.size(), &sc->d.mats)) != RT_OK ||
+        (rc = upload(sc, mesh_mat.data(), mesh_mat.size(), &sc->d.mesh_mat)) != RT_OK) {
+        rt_scene_destroy(sc);
+        return rc;
+    }
+    sc->d.n_lights = n_lights;
+    for (int i = 0; i < n_lights; ++i) {
+        static_assert(sizeof(rt::Light) == sizeof(rt_light_desc), "light layouts must match");
+        memcpy(&sc->d.lights[i], &lights[i], sizeof(rt::Light));
+    }
+    memcpy(sc->d.cam.pos, camera->pos, 12); memcpy(sc->d.cam.up, camera->up, 12);
+    memcpy(sc->d.cam.w, camera->w, 12); memcpy(sc->d.cam.side, camera->side, 12);
+    sc->d.cam.near_clip = camera->near_clip; sc->d.cam.far_clip = camera->far_clip;
+    sc->n_lights = n_lights;
+    sc->n_tris = (int64_t)flat.tris.size();
+    sc->n_inner = (int64_t)flat.nodes.size();
+    sc->n_leaves = flat.n_leaves;
+    sc->max_depth = flat.max_depth;
+    hipError_t e = hipMalloc((void**)&sc->d_counters, 16 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, 16 * sizeof(uint32_t));
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&sc->ev[i]);
+    if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, hipGetErrorString(e)); }
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return RT_OK;
+    for (void* p : sc->owned) (void)hipFree(p);
+    for (auto& b : sc->lv) free_level(b);
+    if (sc->d_counters) (void)hipFree(sc->d_counters);
+    if (sc->h_counters) (void)hipHostFree(sc->h_counters);
+    if (sc->d_stage) (void)hipFree(sc->d_stage);
+    if (sc->d_io) (void)hipFree(sc->d_io);
+    for (auto& e : sc->ev) if (e) (void)hipEventDestroy(e);
+    delete sc;
+    return RT_OK;
+}
+
+int rt_scene_info(const rt_scene* sc, int64_t counts[4]) {
+    if (!sc || !counts) return fail(RT_ERR_INVALID, "rt_scene_info: null argument");
+    counts[0] = sc->n_tris; counts[1] = sc->n_inner; counts[2] = sc->n_leaves; counts[3] = sc->max_depth;
+    return RT_OK;
+}
+
+static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact,
+                      float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* nodes_out, uint32_t* tris_out, void* stream) {
+    if (!sc || n < 0 || (n > 0 && (!org || !dir || !t_out))) return fail(RT_ERR_INVALID, "rt_trace: null argument or negative count");
+    if (n == 0) return RT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(sc->mu);
+    const bool dev = is_device_ptr(org);
+    if (dev != is_device_ptr(dir) || dev != is_device_ptr(t_out)) return fail(RT_ERR_INVALID, "rt_trace: mix of host and device buffers");
+    const float *d_org = org, *d_dir = dir;
+    float *d_t = t_out, *d_n = nrm_out; int32_t* d_tri = tri_out; uint32_t *d_cn = nodes_out, *d_ct = tris_out;
+    if (!dev) {
+        // layout of the staging block: org[3n] dir[3n] t[n] nrm[3n] tri[n] cn[n] ct[n]
+        int rc = ensure_bytes(&sc->d_io, &sc->io_cap, n * 13 * 4);
+        if (rc != RT_OK) return rc;
+        float* base = (float*)sc->d_io;
+        HIP_TRY(hipMemcpyAsync(base, org, n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(base + 3 * n, dir, n * 12, hipMemcpyHostToDevice, s));
+        d_org = base; d_dir = base + 3 * n; d_t = base + 6 * n;
+        d_n = nrm_out ? base + 7 * n : nullptr;
+        d_tri = tri_out ? (int32_t*)(base + 10 * n) : nullptr;
+        d_cn = nodes_out ? (uint32_t*)(base + 11 * n) : nullptr;
+        d_ct = tris_out ? (uint32_t*)(base + 12 * n) : nullptr;
+    }
+    rt::launch_trace(any_hit != 0, exact != 0, sc->d, d_org, d_dir, t0, t1, n, d_t, d_tri, d_n, d_cn, d_ct, s);
+    HIP_TRY(hipGetLastError());
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, s));
+        if (nrm_out) HIP_TRY(hipMemcpyAsync(nrm_out, d_n, n * 12, hipMemcpyDeviceToHost, s));
+        if (tri_out) HIP_TRY(hipMemcpyAsync(tri_out, d_tri, n * 4, hipMemcpyDeviceToHost, s));
+        if (nodes_out) HIP_TRY(hipMemcpyAsync(nodes_out, d_cn, n * 4, hipMemcpyDeviceToHost, s));
+        if (tris_out) HIP_TRY(hipMemcpyAsync(tris_out, d_ct, n * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return RT_OK;
+}
+
+int rt_trace(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact_boxes,
+             float* t_out, int32_t* tri_out, float* nrm_out, void* stream) {
+    return trace_impl(sc, org, dir, t0, t1, n, any_hit, exact_boxes, t_out, tri_out, nrm_out, nullptr, nullptr, stream);
+}
+
+int rt_trace_counted(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact_boxes,
+                     float* t_out, int32_t* tri_out, uint32_t* nodes_out, uint32_t* tris_out, void* stream) {
+    return trace_impl(sc, org, dir, t0, t1, n, any_hit, exact_boxes, t_out, tri_out, nullptr, nodes_out, tris_out, stream);
+}
+
+int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
+    if (!sc || !o || !rgb_out) return fail(RT_ERR_INVALID, "rt_render_rect: null argument");
+    if (o->width <= 0 || o->height <= 0 || x0 < 0 || y0 < 0 || x1 > o->width || y1 > o->height || x0 > x1 || y0 > y1)
+        return fail(RT_ERR_INVALID, "rt_render_rect: rectangle outside the image");
+    if (o->spp < 1 || o->spp > 16 || o->spr < 0 || o->spr > 15 || o->max_bounce < 0 || o->max_bounce > 8 ||
+        o->max_refrac_bounce < 0 || o->max_refrac_bounce > 8)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_rect: spp 1..16, spr 0..15, bounce and rbounce 0..8");
+    if (o->max_bounce + std::max(o->max_bounce, o->max_refrac_bounce) + 1 > rt::RT_MAX_LEVELS)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_rect: bounce depths exceed the level limit");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const int rw = x1 - x0, rh = y1 - y0;
+    if (rw == 0 || rh == 0) return RT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(sc->mu);
+
+    rt::RenderParams P{};
+    P.W = o->width; P.H = o->height; P.x0 = x0; P.y0 = y0; P.rw = rw; P.rh = rh;
+    P.spp = o->spp; P.spr = o->spr; P.D = o->max_bounce; P.Dr = o->max_refrac_bounce;
+    P.eps = o->eps; P.ray_eps = o->ray_eps; P.jitter = o->jitter_mode; P.seed = o->seed;
+    {   // src/render_thread.cpp:34-40 (PI is the float 3.1415926, :3)
+        const float aspect_ratio = o->height / (float)o->width;
+        const float d = sc->d.cam.near_clip;
+        const float a = d * tanf(3.1415926f * o->hfov / 360);
+        P.fl = -a; P.fr = a; P.ft = a * aspect_ratio; P.fb = -P.ft; P.fd = d;
+    }
+    const bool exact = o->exact_boxes != 0;
+    const bool counting = o->count_traversal != 0;
+    uint64_t work[4] = {0, 0, 0, 0};
+    const int spp2 = o->spp * o->spp;
+    const int nl = sc->n_lights;
+
+    // band height: a level-0 budget of samples; scenes that can spawn get a smaller one because levels multiply
+    int64_t budget = sc->any_spawning_material ? (int64_t)1 << 21 : (int64_t)1 << 24;
+    int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
+
+    const bool out_dev = is_device_ptr(rgb_out);
+    float* d_out = rgb_out;
+    if (!out_dev) {
+        int rc = ensure_bytes((void**)&sc->d_stage, &sc->stage_cap, (int64_t)rw * rh * 12);
+        if (rc != RT_OK) return rc;
+        d_out = sc->d_stage;
+    }
+    const bool timing = stats != nullptr;
+    float ms_extend = 0, ms_shadow = 0, ms_shade = 0, ms_total = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if (timing) {
+        HIP_TRY(hipEventCreate(&ev_begin)); HIP_TRY(hipEventCreate(&ev_end));
+        HIP_TRY(hipEventRecord(ev_begin, s));
+    }
+    uint64_t rays_closest = 0, rays_any = 0;
+    int max_levels = 0;
+    unsigned long long* d_traced = (unsigned long long*)(sc->d_counters + 2);
+
+    for (int by = 0; by < rh; by += band_rows) {
+        const int rows = std::min(band_rows, rh - by);
+        const int64_t n_pix = (int64_t)rows * rw;
+        int64_t n = n_pix * spp2;
+        int rc = ensure_level(sc->lv[0], n, nl);
+        if (rc != RT_OK) return rc;
+        rt::launch_generate(sc->d, P, sc->lv[0].L, y0 + by, n, s);
+        int lvl = 0;
+        for (;;) {
+            rt::Level& L = sc->lv[lvl].L;
+            HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint32_t), s));
+            if (nl > 0) HIP_TRY(hipMemsetAsync(L.unocc, 0, (size_t)n * nl * sizeof(uint32_t), s));
+            if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
+            rt::launch_extend(exact, sc->d, P, L, n, sc->d_counters, counting ? (unsigned long long*)(sc->d_counters + 4) : nullptr, s);
+            if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
+            rt::launch_shadow(exact, sc->d, P, L, n * nl * (o->spr + 1), d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
+            if (timing) HIP_TRY(hipEventRecord(sc->ev[2], s));
+            HIP_TRY(hipMemcpyAsync(sc->h_counters, sc->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipGetLastError());
+            if (timing) {
+                float a = 0, b = 0;
+                HIP_TRY(hipEventElapsedTime(&a, sc->ev[0], sc->ev[1]));
+                HIP_TRY(hipEventElapsedTime(&b, sc->ev[1], sc->ev[2]));
+                ms_extend += a; ms_shadow += b;
+            }
+            rays_closest += (uint64_t)n;
+            unsigned long long traced; memcpy(&traced, sc->h_counters + 2, 8);
+            rays_any += traced;
+            for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); work[q] += v; }
+            const int64_t kids = sc->h_counters[0];
+            ++lvl;
+            if (kids == 0) break;
+            if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");
+            rc = ensure_level(sc->lv[lvl], kids, nl);
+            if (rc != RT_OK) return rc;
+            rt::launch_spawn(sc->d, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);
+            n = kids;
+        }
+        max_levels = std::max(max_levels, lvl);
+        rt::LevelSet ls{};
+        for (int q = 0; q < lvl; ++q) ls.lv[q] = sc->lv[q].L;
+        if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
+        rt::launch_replay(sc->d, P, ls, n_pix, d_out + (int64_t)by * rw * 3, s);
+        if (timing) {
+            HIP_TRY(hipEventRecord(sc->ev[1], s));
+            HIP_TRY(hipEventSynchronize(sc->ev[1]));
+            float a = 0; HIP_TRY(hipEventElapsedTime(&a, sc->ev[0], sc->ev[1]));
+            ms_shade += a;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    if (timing) HIP_TRY(hipEventRecord(ev_end, s));
+    if (!out_dev) {
+        HIP_TRY(hipMemcpyAsync(rgb_out, d_out, (size_t)rw * rh * 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (timing) {
+        HIP_TRY(hipEventSynchronize(ev_end));
+        HIP_TRY(hipEventElapsedTime(&ms_total, ev_begin, ev_end));
+        (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
+        stats->rays_closest = rays_closest; stats->rays_any = rays_any;
+        stats->ref_get_hit_calls = 2 * rays_closest + rays_any;
+        stats->ms_total = ms_total; stats->ms_extend = ms_extend; stats->ms_shadow = ms_shadow; stats->ms_shade = ms_shade;
+        stats->levels = max_levels;
+        stats->nodes_extend = work[0]; stats->tris_extend = work[1]; stats->nodes_shadow = work[2]; stats->tris_shadow = work[3];
+    }
+    return RT_OK;
+}
+
+int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* stream) {
+    if (!rgb || !out || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_resolve_u8: null argument or empty image");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)width * height * 3;
+    const bool in_dev = is_device_ptr(rgb), out_dev = is_device_ptr(out);
+    void* tmp = nullptr;
+    const float* d_in = rgb; uint8_t* d_out = out;
+    if (!in_dev || !out_dev) {
+        HIP_TRY(hipMalloc(&tmp, (size_t)n * 5));
+        if (!in_dev) { HIP_TRY(hipMemcpyAsync(tmp, rgb, (size_t)n * 4, hipMemcpyHostToDevice, s)); d_in = (const float*)tmp; }
+        if (!out_dev) d_out = (uint8_t*)tmp + n * 4;
+    }
+    rt::launch_resolve_u8(d_in, width, height, d_out, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !out_dev) e = hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && tmp) e = hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

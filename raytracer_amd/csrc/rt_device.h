@@ -1,0 +1,242 @@
+// Device-side building blocks: float3 helpers that keep the reference's operation order, the slab and
+// triangle tests, the stack traversal, ray generation and the counter-hash random numbers.
+// Compiled with -ffp-contract=off: every * and + below is one IEEE float32 operation unless fmaf is
+// written out, because results are compared bit-for-bit with a CPU that has no fused multiply-add.
+#pragma once
+#include "rt_types.h"
+
+// RT_HD marks code shared by the kernels; a host-only build (used to unit-test kernel bodies without a GPU)
+// defines RT_HOST_EMULATION and supplies float4/int4/atomics itself.
+#ifndef RT_HOST_EMULATION
+#include <hip/hip_runtime.h>
+#define RT_HD __device__ __forceinline__
+#define RT_CLZ(x) __clz(x)
+#define RT_F2I(x) __float_as_int(x)
+#define RT_I2F(x) __int_as_float(x)
+#define RT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define RT_ATOMIC_INC(p) atomicAdd((p), 1u)
+#endif
+
+namespace rt {
+
+struct DScene {
+    const Node64* nodes;
+    const Tri48* tris;
+    const float* nrm;          // [n_tris][9], traversal order
+    const Material* mats;      // per material
+    const int32_t* mesh_mat;   // mesh index -> material index
+    Light lights[8];
+    int32_t n_lights;
+    Camera cam;
+};
+
+struct RenderParams {
+    int32_t W, H;              // full image
+    int32_t x0, y0, rw, rh;    // rect origin and size
+    int32_t spp, spr, D, Dr;
+    float eps, ray_eps;
+    int32_t jitter; uint32_t seed;
+    float fl, fr, fb, ft, fd;  // frustum l, r, b, t and near distance d (src/render_thread.cpp:34-40)
+};
+
+struct V3 { float x, y, z; };
+
+RT_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD V3 v3p(const float* p) { return v3(p[0], p[1], p[2]); }
+RT_HD V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD V3 vscale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+RT_HD V3 vmul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// src/linmath.h:30-37: p = 0; p += b[i]*a[i] for i = 0,1,2
+RT_HD float vdot(V3 a, V3 b) { float p = 0.f; p += b.x * a.x; p += b.y * a.y; p += b.z * a.z; return p; }
+// src/linmath.h:42-46: k = 1/sqrt(v.v); r = v*k
+RT_HD V3 vnorm(V3 a) { float k = 1.f / sqrtf(vdot(a, a)); return vscale(a, k); }
+
+// std::max / std::min as the reference calls them (src/shaders/basic_shaders.cpp:8,26, src/fast_math.cpp:25-27)
+RT_HD float max_std(float a, float b) { return (a < b) ? b : a; }
+RT_HD float min_std(float a, float b) { return (b < a) ? b : a; }
+
+// src/fast_math.cpp:14-22, unrolled from the top bit down: fp(y) = fp(y/2)^2 or x*fp(y/2)*fp(y/2)
+RT_HD float fast_pow_i(float x, int y) {
+    if (y <= 0) return 1.f;
+    float r = 1.f;
+    for (int b = 31 - RT_CLZ(y); b >= 0; --b) r = ((y >> b) & 1) ? x * r * r : r * r;
+    return r;
+}
+
+// ---- counter-hash random numbers ---------------------------------------------------------------------
+RT_HD uint32_t h_mix(uint32_t h, uint32_t v) {
+    h ^= v * 0x9E3779B1u;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+    return h;
+}
+RT_HD uint32_t h_fin(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+enum { SITE_PRIMARY = 1, SITE_SH_LIGHT = 2, SITE_SH_SPLIT = 3, SITE_SHADE_LIGHT = 4, SITE_REFLECT_SPLIT = 5 };
+// the value one rand() call of the reference returns at this call site
+RT_HD int rnd(int jitter, uint32_t seed, uint32_t node, uint32_t site, uint32_t a, uint32_t b) {
+    if (jitter == 0) return 100;
+    return (int)(h_fin(h_mix(h_mix(h_mix(h_mix(seed, node), site), a), b)) >> 1);
+}
+RT_HD uint32_t node_root(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    return h_fin(h_mix(h_mix(seed ^ 0x5bd1e995u, pixel), sample));
+}
+RT_HD uint32_t node_child(uint32_t parent, uint32_t rank) { return h_fin(h_mix(h_mix(parent, 0xC0FFEEu), rank)); }
+
+// ---- primary rays: src/render_thread.cpp:57-79 ----------------------------------------------------------
+// i = column, j = row from the bottom, s = x*spp + y
+RT_HD V3 primary_dir(const DScene& sc, const RenderParams& P, int i, int j, int s, uint32_t node) {
+    const int x = s / P.spp, y = s - x * P.spp;
+    const float unit_len = 1.0f / P.spp;
+    const float jx = rnd(P.jitter, P.seed, node, SITE_PRIMARY, 0, 0) % 100 / 100.0f;
+    const float jy = rnd(P.jitter, P.seed, node, SITE_PRIMARY, 0, 1) % 100 / 100.0f;
+    const float u = P.fl + (P.fr - P.fl) * (i + unit_len * x + jx * unit_len) / P.W;
+    const float v = P.fb + (P.ft - P.fb) * (j + unit_len * y + jy * unit_len) / P.H;
+    V3 du = vscale(v3p(sc.cam.side), u), dv = vscale(v3p(sc.cam.up), v), dw = vscale(v3p(sc.cam.w), -P.fd);
+    return vnorm(vadd(vadd(du, dv), dw));
+}
+
+// ---- lights: src/lights.cpp:13-54 -------------------------------------------------------------------------
+RT_HD V3 light_dir(const Light& L, V3 p, const RenderParams& P, uint32_t node, uint32_t site, uint32_t li) {
+    if (L.kind == 0) return v3p(L.vec);
+    V3 r = vnorm(vsub(v3p(L.vec), p));
+    V3 add;
+    add.x = 0.01f * (rnd(P.jitter, P.seed, node, site, li, 0) % 200 / 100.0f - 1.0f);
+    add.y = 0.01f * (rnd(P.jitter, P.seed, node, site, li, 1) % 200 / 100.0f - 1.0f);
+    add.z = 0.01f * (rnd(P.jitter, P.seed, node, site, li, 2) % 200 / 100.0f - 1.0f);
+    return vnorm(vadd(r, add));
+}
+// src/ray.cpp:47-61: one jittered copy of an exact direction
+RT_HD V3 split_dir(V3 exact, float eps, const RenderParams& P, uint32_t node, uint32_t site, uint32_t a, uint32_t k) {
+    V3 add;
+    add.x = eps * (rnd(P.jitter, P.seed, node, site, a, k * 3 + 0) % 200 / 100.0f - 1.0f);
+    add.y = eps * (rnd(P.jitter, P.seed, node, site, a, k * 3 + 1) % 200 / 100.0f - 1.0f);
+    add.z = eps * (rnd(P.jitter, P.seed, node, site, a, k * 3 + 2) % 200 / 100.0f - 1.0f);
+    return vnorm(vadd(exact, add));
+}
+
+// ---- traversal ---------------------------------------------------------------------------------------------
+struct HitRec { float t; int32_t tri; float beta, gamma; };   // tri = position in traversal order, -1 = none
+
+// Slab test of one box.  EXACT: the reference's arithmetic (src/geometry.cpp:25-37: six true divisions, fmin/fmax
+// that drop NaNs).  Otherwise a multiplication by the precomputed reciprocal replaces each division; tmin is
+// returned for nearest-first ordering and pruning.
+template <bool EXACT>
+RT_HD bool slab(const float* b, V3 o, V3 d, V3 rd, float& tmin) {
+    float t1, t2, t3, t4, t5, t6;
+    if (EXACT) {
+        t1 = (b[0] - o.x) / d.x; t2 = (b[3] - o.x) / d.x;
+        t3 = (b[1] - o.y) / d.y; t4 = (b[4] - o.y) / d.y;
+        t5 = (b[2] - o.z) / d.z; t6 = (b[5] - o.z) / d.z;
+    } else {
+        // (bound - e) * (1/d): the subtraction is the reference's, so d == 0 gives the same +-inf / NaN pattern
+        // as its division (a fused b*rd - e*rd would turn inf - inf into NaN and lose the slab)
+        t1 = (b[0] - o.x) * rd.x; t2 = (b[3] - o.x) * rd.x;
+        t3 = (b[1] - o.y) * rd.y; t4 = (b[4] - o.y) * rd.y;
+        t5 = (b[2] - o.z) * rd.z; t6 = (b[5] - o.z) * rd.z;
+    }
+    tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    return !(tmax < 0.f || tmin > tmax);
+}
+
+#ifndef RT_STACK
+#define RT_STACK 96
+#endif
+
+// Nearest hit (ANY == false) or any hit (ANY == true) with t in [t0, t1].
+// Returns true on a hit.  Nearest: best = (t, position) minimal in (t, position) order, which is the reference's
+// choice among equal t (see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
+// reference's exhaustive recursion (src/geometry.cpp:155-187); otherwise subtrees whose entry distance exceeds the
+// best t so far are skipped and the nearer child is visited first.
+template <bool ANY, bool EXACT>
+RT_HD bool traverse(const DScene& sc, V3 o, V3 d, float t0, float t1, HitRec& best,
+                                         uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+    best.t = INFINITY; best.tri = -1; best.beta = 0.f; best.gamma = 0.f;
+    V3 rd = v3(0, 0, 0);
+    if (!EXACT) rd = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    int32_t stack[RT_STACK];
+    int sp = 0;
+    int32_t cur = 0;
+    bool found = false;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (n_nodes) ++*n_nodes;
+            const float lb[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+            const float rb[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+            const int32_t lref = RT_F2I(q3.x), rref = RT_F2I(q3.y);
+            float tl, tr;
+            bool hl = slab<EXACT>(lb, o, d, rd, tl);
+            bool hr = (rref != RT_NONE) && slab<EXACT>(rb, o, d, rd, tr);
+            if (!EXACT) {
+                const float lim = ANY ? t1 : best.t;
+                hl = hl && !(tl > lim); hr = hr && !(tr > lim);
+            }
+            if (hl && hr) {
+                int32_t near_ = lref, far_ = rref;
+                if (!EXACT && tr < tl) { near_ = rref; far_ = lref; }
+                if (sp < RT_STACK) stack[sp++] = far_;
+                cur = near_;
+                continue;
+            }
+            if (hl) { cur = lref; continue; }
+            if (hr) { cur = rref; continue; }
+        } else {
+            int32_t k = ~cur;
+            int32_t run = 1;
+            do {
+                const float4* tp = reinterpret_cast<const float4*>(sc.tris + k);
+                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                if (n_tris) ++*n_tris;
+                if (k == ~cur) run = RT_F2I(p0.w);
+                // src/geometry.cpp:268-295 (Cramer's rule), same names
+                const float a_ = p1.x, b_ = p1.y, c_ = p1.z;
+                const float d_ = p2.x, e_ = p2.y, f_ = p2.z;
+                const float g_ = d.x, h_ = d.y, i_ = d.z;
+                const float j_ = p0.x - o.x, k_ = p0.y - o.y, l_ = p0.z - o.z;
+                const float ei_hf = e_ * i_ - h_ * f_;
+                const float gf_di = g_ * f_ - d_ * i_;
+                const float dh_eg = d_ * h_ - e_ * g_;
+                const float ak_jb = a_ * k_ - j_ * b_;
+                const float jc_al = j_ * c_ - a_ * l_;
+                const float bl_kc = b_ * l_ - k_ * c_;
+                const float m = a_ * ei_hf + b_ * gf_di + c_ * dh_eg;
+                const float t = (f_ * ak_jb + e_ * jc_al + d_ * bl_kc) / -m;
+                bool ok = !(t < t0 || t > t1);
+                if (!ANY) ok = ok && !(t > best.t);
+                if (ok) {
+                    const float gamma = (i_ * ak_jb + h_ * jc_al + g_ * bl_kc) / m;
+                    if (!(gamma < 0.f || gamma > 1.f)) {
+                        const float beta = (j_ * ei_hf + k_ * gf_di + l_ * dh_eg) / m;
+                        if (!(beta < 0.f || beta > (1.f - gamma))) {
+                            // a NaN t (0/0 on a zero-area triangle) passes every comparison above; it is never a hit here
+                            if (ANY) { if (t == t) return true; }
+                            else if (t < best.t || (t == best.t && k < best.tri)) {
+                                best.t = t; best.tri = k; best.beta = beta; best.gamma = gamma;
+                                found = true;
+                            }
+                        }
+                    }
+                }
+                ++k;
+            } while (--run > 0);
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return found;
+}
+
+// src/geometry.cpp:297-306: interpolated unit normal of the hit
+RT_HD V3 hit_normal(const DScene& sc, const HitRec& h) {
+    const float* n = sc.nrm + (size_t)h.tri * 9;
+    const float alpha = 1.f - h.gamma - h.beta;
+    V3 pn = vscale(v3p(n), alpha), bf = vscale(v3p(n + 3), h.beta), gf = vscale(v3p(n + 6), h.gamma);
+    return vnorm(vadd(vadd(pn, bf), gf));
+}
+
+}  // namespace rt

@@ -1,0 +1,363 @@
+// Kernel bodies of the wavefront pipeline.  One call = the work of one lane; the __global__ wrappers in
+// rt_kernels.hip only compute the lane's index and reduce counters.
+//
+// Pipeline for one band of pixels (all stages cite the reference's src/render_thread.cpp):
+//   generate : level-0 nodes = primary render rays (:57-94)
+//   per level, while the level is not empty:
+//     extend : nearest hit of every node's ray (:122 for render rays; the shadow-type twin that the reference
+//              traces along the same ray, :97-104 / :269-280, has the same answer and is not traced again)
+//     shadow : the light-visibility rays of every node's companion shadow ray (:134-171), any-hit
+//     spawn  : children of reflective / refractive hits (:207-283, :300-397) into the next level
+//   replay   : per pixel, walks the stored tree in the reference's LIFO pop order and does all colour
+//              arithmetic (:128-438) and the final sum/weight division (src/rasterizer.cpp:88-103) in that order.
+// Splitting geometry (which rays exist and what they hit) from colour is possible because no ray's direction
+// depends on a colour; it makes the float sums happen in exactly the reference's order.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+enum { RAY_SHADOW = 0, RAY_REFLECT = 1, RAY_REFRACTIVE = 2 };   // src/ray.h:10-14
+enum { RT_MAX_LEVELS = 20 };
+
+struct Level {
+    float4* org;       // xyz ray origin, w = bits(path key)
+    float4* dir;       // xyz ray direction, w = weight (src/ray.h:36)
+    int4* meta;        // x parent index in the previous level (-1 at level 0), y = type | depth<<8 | rank<<16,
+                       // z = bits(refraci), w = index (this level) of the node whose ray the companion shadow ray repeats
+    float4* hit;       // xyz unit normal at the hit, w = t
+    int32_t* tri;      // triangle position (traversal order) or -1
+    int2* kids;        // x = first child in the next level (-1: none), y = number of children
+    float* aux;        // Schlick term r_theta of a refractive spawn
+    uint32_t* unocc;   // [n][n_lights] light rays that reached the light, out of spr+1
+};
+
+RT_HD int meta_type(int y) { return y & 0xff; }
+RT_HD int meta_depth(int y) { return (y >> 8) & 0xff; }
+RT_HD int meta_rank(int y) { return (y >> 16) & 0xff; }
+RT_HD int meta_pack(int type, int depth, int rank) { return type | (depth << 8) | (rank << 16); }
+
+RT_HD V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
+RT_HD float4 mk4(V3 a, float w) { float4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = w; return r; }
+RT_HD V3 point_at(V3 e, V3 d, float t) { return vadd(e, vscale(d, t)); }    // src/ray.cpp:32-35
+
+// ---------------------------------------------------------------------------------------------- generate
+// g = (row_in_band * rw + column_in_rect) * spp^2 + sample; band_y0 = first image row of the band
+RT_HD void body_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int64_t g) {
+    const int spp2 = P.spp * P.spp;
+    const int pl = (int)(g / spp2), s = (int)(g - (int64_t)pl * spp2);
+    const int i = P.x0 + pl % P.rw, j = band_y0 + pl / P.rw;
+    const uint32_t key = node_root(P.seed, (uint32_t)(j * P.W + i), (uint32_t)s);
+    const V3 d = primary_dir(sc, P, i, j, s, key);
+    L.org[g] = mk4(v3p(sc.cam.pos), RT_I2F((int)key));
+    L.dir[g] = mk4(d, 1.f);
+    int4 m; m.x = -1; m.y = meta_pack(RAY_REFLECT, P.D, 0); m.z = RT_F2I(1.f); m.w = (int)g;
+    L.meta[g] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ extend
+// src/ray.cpp:63-96.  Returns the Schlick term; out = refracted direction (valid when the term is >= 0).
+RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
+    const float dn = vdot(d, norm);
+    V3 term1 = vscale(norm, -1 * dn);
+    term1 = vadd(d, term1);
+    term1 = vscale(term1, n / nt);
+    const float q = n / nt;
+    const V3 term2 = vscale(norm, sqrtf(1 - (q * q) * (1 - dn * dn)));
+    const V3 tvec = vsub(term1, term2);
+    float c;
+    if (dn < 0) c = -dn; else c = vdot(tvec, norm);
+    const float rr = (nt - 1) / (nt + 1);
+    const float r0 = rr * rr;
+    const float r_theta = r0 + (1 - r0) * fast_pow_i(1 - c, 5);
+    if (r_theta < 0) return r_theta;
+    out = vnorm(tvec);
+    return r_theta;
+}
+
+// returns the number of children this node will spawn
+template <bool EXACT>
+RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, int64_t i,
+                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+    const V3 o = f4v(L.org[i]), d = f4v(L.dir[i]);
+    HitRec h;
+    const bool hit = traverse<false, EXACT>(sc, o, d, P.eps, INFINITY, h, n_nodes, n_tris);
+    int2 kd; kd.x = -1; kd.y = 0;
+    L.kids[i] = kd;
+    if (!hit) {
+        L.hit[i] = mk4(v3(0, 0, 0), INFINITY);
+        L.tri[i] = -1;
+        return 0;
+    }
+    const V3 n = hit_normal(sc, h);
+    L.hit[i] = mk4(n, h.t);
+    L.tri[i] = h.tri;
+    const Material& M = sc.mats[sc.mesh_mat[sc.tris[h.tri].mesh]];
+    const int4 m = L.meta[i];
+    const int depth = meta_depth(m.y);
+    if (depth > 0 && M.kind == 2) return P.spr + 1;
+    if (depth > 0 && M.kind == 3) {
+        V3 td;
+        const float r_theta = refract_dir(d, n, RT_I2F(m.z), M.refractivity, td);
+        L.aux[i] = r_theta;
+        return (r_theta <= 0) ? 1 : 2;                              // src/render_thread.cpp:345
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ shadow
+// w = (node * n_lights + light) * (spr + 1) + k.  Returns 1 if a ray was traced.
+template <bool EXACT>
+RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, int64_t w,
+                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+    const int per = P.spr + 1;
+    const int64_t nl = w / per;
+    const int k = (int)(w - nl * per);
+    const int64_t i = nl / sc.n_lights;
+    const int li = (int)(nl - i * sc.n_lights);
+    const int comp = L.meta[i].w;
+    if (L.tri[comp] < 0) return 0;                                  // the shadow-type ray missed: record stays stale
+    const V3 p = point_at(f4v(L.org[comp]), f4v(L.dir[comp]), L.hit[comp].w);
+    const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
+    const V3 exact = vnorm(light_dir(sc.lights[li], p, P, key, SITE_SH_LIGHT, (uint32_t)li));   // Ray ctor normalises
+    const V3 d = (k < P.spr) ? split_dir(exact, P.ray_eps, P, key, SITE_SH_SPLIT, (uint32_t)li, (uint32_t)k) : exact;
+    HitRec h;
+    const bool occluded = traverse<true, EXACT>(sc, p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris);
+    if (!occluded) RT_ATOMIC_INC(&L.unocc[i * sc.n_lights + li]);
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------- spawn
+RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
+    const int tri = L.tri[i];
+    if (tri < 0) return;
+    const int4 m = L.meta[i];
+    const int depth = meta_depth(m.y);
+    const Material& M = sc.mats[sc.mesh_mat[sc.tris[tri].mesh]];
+    if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
+    const V3 o = f4v(L.org[i]), d = f4v(L.dir[i]);
+    const float4 hn = L.hit[i];
+    const V3 n = f4v(hn);
+    const float t = hn.w;
+    const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
+    const float weight = L.dir[i].w;
+    const V3 p = point_at(o, d, t);
+    // mirror direction, src/linmath.h:59-65
+    const float pp = 2.f * vdot(d, n);
+    const V3 rd = v3(d.x - pp * n.x, d.y - pp * n.y, d.z - pp * n.z);
+    if (M.kind == 2) {                                              // src/render_thread.cpp:239-280
+        const int cnt = P.spr + 1;
+        const uint32_t base = RT_ATOMIC_ADD(next_count, (uint32_t)cnt);
+        for (int k = 0; k < cnt; ++k) {
+            const V3 dk = (k < P.spr) ? split_dir(rd, P.ray_eps, P, key, SITE_REFLECT_SPLIT, 0, (uint32_t)k) : rd;
+            const uint32_t ck = node_child(key, (uint32_t)k);
+            N.org[base + k] = mk4(p, RT_I2F((int)ck));
+            N.dir[base + k] = mk4(dk, weight);
+            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = m.z; cm.w = (int)(base + P.spr);
+            N.meta[base + k] = cm;
+        }
+        int2 kd; kd.x = (int)base; kd.y = cnt;
+        L.kids[i] = kd;
+    } else {                                                        // src/render_thread.cpp:318-394
+        const float refraci = RT_I2F(m.z);
+        V3 td = v3(0, 0, 0);
+        const float r_theta = refract_dir(d, n, refraci, M.refractivity, td);
+        const bool both = !(r_theta <= 0);
+        const int cnt = both ? 2 : 1;
+        const uint32_t base = RT_ATOMIC_ADD(next_count, (uint32_t)cnt);
+        const int d_rf = (refraci == 1) ? P.D : depth - 1;
+        const int d_rt = (refraci == 1) ? P.Dr : depth - 1;
+        const int zi = RT_F2I(M.refractivity);
+        {
+            N.org[base] = mk4(p, RT_I2F((int)node_child(key, 0)));
+            N.dir[base] = mk4(rd, both ? r_theta * weight : weight);
+            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFRACTIVE, d_rf, 0); cm.z = zi; cm.w = (int)base;
+            N.meta[base] = cm;
+        }
+        if (both) {
+            N.org[base + 1] = mk4(p, RT_I2F((int)node_child(key, 1)));
+            N.dir[base + 1] = mk4(td, (1 - r_theta) * weight);
+            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFRACTIVE, d_rt, 1); cm.z = zi; cm.w = (int)(base + 1);
+            N.meta[base + 1] = cm;
+        }
+        int2 kd; kd.x = (int)base; kd.y = cnt;
+        L.kids[i] = kd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ replay
+// src/shaders/basic_shaders.cpp:6-13
+RT_HD V3 lambert_shade(V3 ca, V3 cr, V3 cl, V3 n, V3 l) {
+    const float r = max_std(0.0f, vdot(n, l));
+    V3 c = vscale(cl, r);
+    c = vadd(c, ca);
+    return vmul(cr, c);
+}
+// src/shaders/basic_shaders.cpp:17-30
+RT_HD V3 phong_shade(V3 cl, V3 cp, V3 l, V3 e, V3 n, int p, V3 clambert) {
+    V3 r = vscale(n, 2.0f * vdot(l, n));
+    r = vsub(r, l);
+    r = vnorm(r);
+    V3 cph = vscale(cp, fast_pow_i(max_std(0.0f, vdot(e, r)), p));
+    cph = vmul(cl, cph);
+    V3 c = vadd(clambert, cph);
+    c.x = min_std(1.0f, c.x); c.y = min_std(1.0f, c.y); c.z = min_std(1.0f, c.z);
+    return c;
+}
+// src/materials.cpp:4-8,28-43,68-88,120-140
+RT_HD V3 apply_shade(const DScene& sc, const RenderParams& P, const Material& M, V3 p, V3 n, const float* sh, uint32_t key) {
+    if (M.kind == 0) return v3(1.f, 1.f, 0.f);
+    V3 r = v3(0, 0, 0);
+    V3 view = v3(0, 0, 0);
+    if (M.kind != 1) view = vnorm(vsub(v3p(sc.cam.pos), p));
+    for (int li = 0; li < sc.n_lights; ++li) {
+        const V3 l = light_dir(sc.lights[li], p, P, key, SITE_SHADE_LIGHT, (uint32_t)li);
+        const V3 lc = v3p(sc.lights[li].color);
+        V3 c_add = lambert_shade(v3p(M.ambient), v3p(M.base), lc, n, l);
+        if (M.kind != 1) c_add = phong_shade(lc, v3p(M.spec), l, view, n, (int)M.shininess, c_add);
+        c_add = vscale(c_add, sh[li]);
+        r = vadd(r, c_add);
+    }
+    return r;
+}
+
+// What a node leaves behind for its children while the replay is below it.
+struct RFrame {
+    int32_t base, next;       // first child, next child to pop (counts down: the last pushed pops first)
+    int32_t refr, count;      // children of a refractive hit; how many
+    float r_theta;            // Schlick term of a refractive hit
+    V3 c; float contrib, tpc; // colour state handed to the children (src/render_thread.cpp:245-248, :348, :367-382)
+};
+
+// One pixel: pl = row_in_band * rw + column_in_rect.  Writes rgb_out[pl] = sum(colours) / sum(weights).
+RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out) {
+    const int spp2 = P.spp * P.spp;
+    const float Dr = (float)P.Dr;
+    float shadow_rec[8];
+    for (int q = 0; q < 8; ++q) shadow_rec[q] = 1.f;
+    V3 sum = v3(0, 0, 0), wsum = v3(0, 0, 0);
+    RFrame fr[RT_MAX_LEVELS];
+    // push order of src/render_thread.cpp:57-109 is sample 0 first, so the last sample pops first
+    for (int s = spp2 - 1; s >= 0; --s) {
+        int lvl = 0;
+        int64_t i = pl * spp2 + s;
+        V3 cc = v3(0, 0, 0);
+        float contrib = 1.f, tpc = 0.f;
+        for (;;) {
+            // ---- pop one render ray: node i of level lvl with colour state (cc, contrib, tpc)
+            const Level& L = lv[lvl];
+            const int4 m = L.meta[i];
+            const int type = meta_type(m.y), depth = meta_depth(m.y);
+            const float weight = L.dir[i].w;
+            // its companion shadow-type ray pops just before it (:134-171)
+            if (L.tri[m.w] >= 0)
+                for (int li = 0; li < sc.n_lights; ++li) {
+                    float sh_frac = (float)L.unocc[i * sc.n_lights + li];    // +1 per light ray that hit nothing
+                    sh_frac /= (float)(P.spr + 1);
+                    shadow_rec[li] = sh_frac;
+                }
+            const int tri = L.tri[i];
+            bool draw = false, has_kids = false;
+            V3 c = v3(0, 0, 0);
+            if (tri >= 0) {
+                const Material& M = sc.mats[sc.mesh_mat[sc.tris[tri].mesh]];
+                const float4 hn = L.hit[i];
+                const V3 n = f4v(hn);
+                const V3 p = point_at(f4v(L.org[i]), f4v(L.dir[i]), hn.w);
+                const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
+                const bool use_refl = (M.kind == 2 || M.kind == 3), use_refr = (M.kind == 3);
+                if (!use_refl) {                                                 // :187-200
+                    V3 add = apply_shade(sc, P, M, p, n, shadow_rec, key);
+                    if (contrib != 1) add = vscale(add, 1 - tpc);
+                    cc = vadd(cc, add);
+                    c = cc; draw = true;
+                } else if (depth > 0 && !use_refr) {                             // :207-283
+                    float prev = M.reflectivity;
+                    contrib = 1 - prev;
+                    for (int q = depth; q < P.D; ++q) { contrib = prev * (1 - M.reflectivity); prev = prev - contrib; }
+                    V3 self = apply_shade(sc, P, M, p, n, shadow_rec, key);
+                    self = vscale(self, contrib);
+                    if (depth == P.D) cc = self; else cc = vadd(cc, self);
+                    tpc += contrib;
+                    const int2 kd = L.kids[i];
+                    RFrame& F = fr[lvl];
+                    F.base = kd.x; F.count = kd.y; F.next = kd.y - 1; F.refr = 0; F.r_theta = 0.f;
+                    F.c = cc; F.contrib = contrib; F.tpc = tpc;
+                    has_kids = kd.y > 0;
+                } else if (depth <= 0) {                                         // :286-293, :400-406
+                    c = cc; draw = true;
+                } else {                                                         // :300-397
+                    V3 c_add;
+                    if (RT_I2F(m.z) == M.refractivity) {
+                        c_add.x = M.transp[0] * expf(-M.transp[0] * hn.w);
+                        c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
+                        c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);
+                    } else c_add = v3(1, 1, 1);
+                    const int2 kd = L.kids[i];
+                    RFrame& F = fr[lvl];
+                    F.base = kd.x; F.count = kd.y; F.next = kd.y - 1; F.refr = 1; F.r_theta = L.aux[i];
+                    F.c = vmul(cc, c_add); F.contrib = 1.f; F.tpc = 0.f;
+                    has_kids = kd.y > 0;
+                }
+            } else {                                                             // :414-430
+                if ((type == RAY_REFLECT && depth < P.D) || (type == RAY_REFRACTIVE && depth < Dr)) { c = cc; draw = true; }
+            }
+            if (draw) {                                                          // :434-438 and src/rasterizer.cpp:92-96
+                sum = vadd(sum, c);
+                wsum = vadd(wsum, v3(weight, weight, weight));
+            }
+            // ---- next ray to pop: the newest pushed one
+            if (!has_kids) {
+                --lvl;
+                while (lvl >= 0 && fr[lvl].next < 0) --lvl;
+                if (lvl < 0) break;
+            }
+            const RFrame& F = fr[lvl];
+            const int k = fr[lvl].next--;
+            i = F.base + k;
+            cc = F.c; contrib = F.contrib; tpc = F.tpc;
+            if (F.refr && F.count == 2) cc = vscale(cc, k == 0 ? F.r_theta : 1 - F.r_theta);   // :368, :382
+            ++lvl;
+        }
+    }
+    rgb_out[pl * 3 + 0] = sum.x / wsum.x;
+    rgb_out[pl * 3 + 1] = sum.y / wsum.y;
+    rgb_out[pl * 3 + 2] = sum.z / wsum.z;
+}
+
+// ------------------------------------------------------------------------------------------- batch trace
+template <bool ANY, bool EXACT>
+RT_HD void body_trace(const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t i,
+                      float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cnt_nodes, uint32_t* cnt_tris) {
+    const V3 o = v3p(org + 3 * i), d = v3p(dir + 3 * i);
+    HitRec h;
+    uint32_t nn = 0, nt = 0;
+    const bool hit = traverse<ANY, EXACT>(sc, o, d, t0, t1, h, cnt_nodes ? &nn : nullptr, cnt_tris ? &nt : nullptr);
+    if (ANY) {
+        t_out[i] = hit ? 0.f : INFINITY;
+        if (tri_out) tri_out[i] = hit ? 0 : -1;
+    } else {
+        t_out[i] = hit ? h.t : INFINITY;
+        if (tri_out) tri_out[i] = hit ? sc.tris[h.tri].id : -1;
+        if (nrm_out) {
+            const V3 n = hit ? hit_normal(sc, h) : v3(0, 0, 0);
+            nrm_out[3 * i] = n.x; nrm_out[3 * i + 1] = n.y; nrm_out[3 * i + 2] = n.z;
+        }
+    }
+    if (cnt_nodes) cnt_nodes[i] = nn;
+    if (cnt_tris) cnt_tris[i] = nt;
+}
+
+// src/main.cpp:157-167: out row 0 is the top; (int) of a NaN or out-of-range double is INT_MIN on x86-64
+RT_HD void body_resolve_u8(const float* rgb, int W, int H, int64_t i, uint8_t* out) {
+    const int64_t px = i / 3; const int c = (int)(i - px * 3);
+    const int y = (int)(px / W), x = (int)(px - (int64_t)y * W);
+    const float v = rgb[((int64_t)(H - y - 1) * W + x) * 3 + c];
+    const double s = floor((double)v * 256.0);
+    int q;
+    if (!(s == s) || s >= 2147483648.0 || s < -2147483648.0) q = INT32_MIN; else q = (int)s;
+    q = q > 255 ? 255 : q; q = q < 0 ? 0 : q;
+    out[i] = (uint8_t)q;
+}
+
+}  // namespace rt

@@ -1,0 +1,121 @@
+// __global__ wrappers and launchers of the wavefront pipeline (bodies: rt_kernels.h).
+#include "rt_launch.h"
+
+namespace rt {
+namespace {
+
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_generate(DScene sc, RenderParams P, Level L, int band_y0, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g < n) body_generate(sc, P, L, band_y0, g);
+}
+
+// work[0] += inner nodes fetched, work[1] += triangles tested (COUNT builds only)
+template <bool COUNT>
+__device__ __forceinline__ void add_work(unsigned long long* work, uint32_t nn, uint32_t nt) {
+    if (COUNT) {
+        nn = wave_sum(nn); nt = wave_sum(nt);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&work[0], (unsigned long long)nn); atomicAdd(&work[1], (unsigned long long)nt); }
+    }
+}
+
+template <bool EXACT, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t kids = 0, nn = 0, nt = 0;
+    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    kids = wave_sum(kids);
+    if ((threadIdx.x & 63) == 0 && kids) atomicAdd(&counters[0], kids);
+    add_work<COUNT>(work, nn, nt);
+}
+
+template <bool EXACT, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, unsigned long long* traced, unsigned long long* work) {
+    const int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t did = 0, nn = 0, nt = 0;
+    if (w < n_items) did = (uint32_t)body_shadow<EXACT>(sc, P, L, w, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    did = wave_sum(did);
+    if ((threadIdx.x & 63) == 0 && did) atomicAdd(traced, (unsigned long long)did);
+    add_work<COUNT>(work, nn, nt);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_spawn(DScene sc, RenderParams P, Level L, Level N, int64_t n, uint32_t* cursor) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) body_spawn(sc, P, L, N, cursor, i);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_replay(DScene sc, RenderParams P, LevelSet ls, int64_t n_pixels, float* rgb_out) {
+    const int64_t pl = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pl < n_pixels) body_replay(sc, P, ls.lv, pl, rgb_out);
+}
+
+template <bool ANY, bool EXACT>
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float* org, const float* dir, float t0, float t1, int64_t n,
+                                                 float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) body_trace<ANY, EXACT>(sc, org, dir, t0, t1, i, t_out, tri_out, nrm_out, cn, ct);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve_u8(const float* rgb, int W, int H, int64_t n, uint8_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) body_resolve_u8(rgb, W, H, i, out);
+}
+
+inline unsigned blocks(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+void launch_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int64_t n, hipStream_t s) {
+    if (n > 0) k_generate<<<blocks(n), BLOCK, 0, s>>>(sc, P, L, band_y0, n);
+}
+void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
+                   unsigned long long* work, hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned g = blocks(n);
+    if (work) {
+        if (exact) k_extend<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
+        else k_extend<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
+    } else {
+        if (exact) k_extend<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
+        else k_extend<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
+    }
+}
+void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,
+                   unsigned long long* work, hipStream_t s) {
+    if (n_items <= 0) return;
+    const unsigned g = blocks(n_items);
+    if (work) {
+        if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, work);
+        else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, work);
+    } else {
+        if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, nullptr);
+        else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, nullptr);
+    }
+}
+void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s) {
+    if (n > 0) k_spawn<<<blocks(n), BLOCK, 0, s>>>(sc, P, L, N, n, cursor);
+}
+void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_pixels, float* rgb_out, hipStream_t s) {
+    if (n_pixels > 0) k_replay<<<blocks(n_pixels), BLOCK, 0, s>>>(sc, P, ls, n_pixels, rgb_out);
+}
+void launch_trace(bool any, bool exact, const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t n,
+                  float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct, hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned g = blocks(n);
+    if (any && exact) k_trace<true, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
+    else if (any) k_trace<true, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
+    else if (exact) k_trace<false, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
+    else k_trace<false, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
+}
+void launch_resolve_u8(const float* rgb, int W, int H, uint8_t* out, hipStream_t s) {
+    const int64_t n = (int64_t)W * H * 3;
+    if (n > 0) k_resolve_u8<<<blocks(n), BLOCK, 0, s>>>(rgb, W, H, n, out);
+}
+
+}  // namespace rt

@@ -1,0 +1,23 @@
+// Launchers of the pipeline kernels (defined in rt_kernels.hip), called by the C-ABI layer.
+#pragma once
+#include "rt_kernels.h"
+
+namespace rt {
+
+struct LevelSet { Level lv[RT_MAX_LEVELS]; };
+
+void launch_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int64_t n, hipStream_t s);
+// counters[0] += number of children the level will spawn
+// work (may be NULL): work[0] += inner nodes fetched, work[1] += triangles tested
+void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
+                   unsigned long long* work, hipStream_t s);
+// *traced += light rays traced
+void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,
+                   unsigned long long* work, hipStream_t s);
+void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s);
+void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_pixels, float* rgb_out, hipStream_t s);
+void launch_trace(bool any, bool exact, const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t n,
+                  float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct, hipStream_t s);
+void launch_resolve_u8(const float* rgb, int W, int H, uint8_t* out, hipStream_t s);
+
+}  // namespace rt

@@ -1,0 +1,84 @@
+"""Host-side logic that needs no GPU: scene files, option files, the C-ABI's exported symbols, band sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api, scenes
+from raytracer_amd._abi import MaterialDesc, LightDesc, CameraDesc, Options, Stats
+from raytracer_amd.options import parse_options
+from raytracer_amd.scene import Scene
+from tests.conftest import GOLDEN, ROOT
+
+
+def test_scene_roundtrip(tmp_path):
+    sc = scenes.glass_balls(6)
+    p = str(tmp_path / "s.rtscene")
+    sc.save(p)
+    sc2 = Scene.load(p)
+    assert [m.name for m in sc2.meshes] == [m.name for m in sc.meshes]
+    for a, b in zip(sc.meshes, sc2.meshes):
+        assert a.material == b.material and (a.pos == b.pos).all() and (a.nrm == b.nrm).all()
+    assert all((x.packed() == y.packed()).all() for x, y in zip(sc.materials, sc2.materials))
+    assert all((x.packed() == y.packed()).all() for x, y in zip(sc.lights, sc2.lights))
+    assert (sc.camera.packed() == sc2.camera.packed()).all()
+
+
+def test_baked_reference_scenes_have_the_reference_triangle_counts():
+    want = {"stanford_bunny": [200, 4968, 2696], "simple_knife": [27212], "unit_cube": [108], "unit_sphere": [760],
+            "unit_cylinder": [240], "2020_plane_light": [200]}
+    for name, counts in want.items():
+        sc = Scene.load(os.path.join(GOLDEN, name + ".rtscene"))
+        assert [m.n_tris for m in sc.meshes] == counts
+
+
+def test_duplicate_mesh_names_rejected():
+    sc = scenes.bunny()
+    sc.meshes[1].name = sc.meshes[0].name
+    with pytest.raises(ValueError):
+        sc.validate()
+
+
+def test_option_file_keys():
+    # the keys of the reference's option file (reference README.md:212-250, src/options.txt)
+    text = "-dispw 1920\n-disph 1080\n-mpbs 200\n-hfov 60\n-spp 2\n-bounce 3\n-spr 3\n-eps 0.0001\n-reps 0.1\n-rbounce 5\n\n-unknown 1\n"
+    opt, extra = parse_options(text)
+    assert (opt.width, opt.height, opt.spp, opt.spr, opt.max_bounce, opt.max_refrac_bounce) == (1920, 1080, 2, 3, 3, 5)
+    assert abs(opt.hfov - 60) < 1e-6 and abs(opt.eps - 1e-4) < 1e-10 and abs(opt.ray_eps - 0.1) < 1e-8
+    assert extra["mpbs"] == 200
+    d = Options()     # the reference's defaults, src/main.cpp:74-75,103-111
+    assert (d.width, d.height, d.spp, d.spr, d.max_bounce, d.max_refrac_bounce) == (960, 540, 2, 4, 3, 3)
+
+
+def test_abi_struct_sizes():
+    assert ctypes.sizeof(MaterialDesc) == 64 and ctypes.sizeof(LightDesc) == 32 and ctypes.sizeof(CameraDesc) == 64
+    assert ctypes.sizeof(Options) == 64 and ctypes.sizeof(Stats) == 88
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|const char\*)\s+(rt_\w+)\s*\(", header, flags=re.M)))
+    assert declared == sorted(api.EXPORTS)
+    L = api.lib()       # raises if librt_amd.so was not built
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_compute_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.RtError):
+        api.init()
+
+
+def test_band_schedule_covers_every_row_once():
+    from raytracer_amd.distributed import band_schedule
+    for h, n, b in [(1080, 8, 8), (1077, 3, 16), (5, 8, 8), (2160, 8, 12)]:
+        sched = band_schedule(h, n, b)
+        rows = sorted(y for bands in sched for y0, y1 in bands for y in range(y0, y1))
+        assert rows == list(range(h))
+        sizes = [sum(y1 - y0 for y0, y1 in bands) for bands in sched]
+        assert max(sizes) - min(sizes) <= b
