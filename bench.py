@@ -1,0 +1,192 @@
+"""Headline benchmark: Mrays/s of the ray-tracing hot path on the reference's bunny frame.
+
+One step = one whole frame through the hot path (generate, nearest-hit, light-visibility rays, colour replay) with the
+scene resident in HBM and the framebuffer written to HBM.  With N > 1 GPUs the frame is sharded by interleaved row
+bands (scene replicated per GPU, no exchange while tracing) and the rows are all-gathered over RCCL each step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bunny_lambert_1080p]
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from raytracer_amd import api, scenes  # noqa: E402
+from raytracer_amd._abi import Options, RT_JITTER_HASH  # noqa: E402
+from raytracer_amd.distributed import band_schedule, gather_frame, render_local_bands  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, datasheet
+BAND_ROWS = 8
+
+WORKLOADS = {
+    # BASELINE.json configs[0] / the target of its north_star: the shipped Stanford-bunny scene, Lambert, shadow rays,
+    # -spp 2 (4 samples per pixel), -spr 3, 3 bounces, 1920x1080 (reference README.md:26-40)
+    "bunny_lambert_1080p": (lambda: scenes.bunny(), dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3,
+                                                          eps=1e-4, ray_eps=0.1)),
+    # configs[1]: ground and dome Phong-reflective, 2 bounces (README.md:42-56)
+    "bunny_phong_1080p": (lambda: scenes.bunny(phong_surroundings=True),
+                          dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, ray_eps=0.1)),
+    "mirror_room": (lambda: scenes.mirror_room(), dict(width=1827, height=1077, hfov=60, spp=2, spr=3, max_bounce=3,
+                                                        eps=1e-3, ray_eps=0.01)),
+    "glass_balls": (lambda: scenes.glass_balls(), dict(width=1920, height=1080, hfov=54.5, spp=2, spr=4, max_bounce=3,
+                                                        max_refrac_bounce=5, eps=1e-3, ray_eps=0.1)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bunny_lambert_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    api.init(-1)
+
+    make, kw = WORKLOADS[args.workload]
+    scene = make()
+    opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=0, **kw)
+    W, H = opt.width, opt.height
+    tracer = api.TracerScene(scene)
+    stream = torch.cuda.current_stream().cuda_stream
+    bands = band_schedule(H, world, BAND_ROWS)[rank] if world > 1 else [(0, H)]
+
+    def render_rect(x0, y0, x1, y1, out, stats=False):
+        return tracer.render_rect(opt, x0, y0, x1, y1, out=out, stats=stats, stream=stream)[1]
+
+    def step():
+        local = render_local_bands(render_rect, bands, W, dev)
+        return gather_frame(local, H, W, world, BAND_ROWS) if world > 1 else local
+
+    # rays per frame on this rank (the same every step: the seed is fixed)
+    rays_local = 0
+    for y0, y1 in bands:
+        st = render_rect(0, y0, W, y1, torch.empty((y1 - y0, W, 3), dtype=torch.float32, device=dev), stats=True)
+        rays_local += st.rays_closest + st.rays_any
+    rays = torch.tensor([float(rays_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays)
+    rays_frame = float(rays.item())
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = rays_frame / (dt / args.steps) / 1e6
+
+    result = {
+        "metric": "Mrays/s (primary+secondary), whole 1080p 4spp frame through the hot path",
+        "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "reference scene fixture (input_files/defaultScene/stanford_bunny.fbx baked to .rtscene), "
+                                "counter-hash jitter seed 1",
+        "config": {"workload": args.workload, "width": W, "height": H, "spp": opt.spp * opt.spp, "spr": opt.spr + 1,
+                   "max_bounce": opt.max_bounce, "triangles": scene.n_tris, "lights": len(scene.lights),
+                   "rays_per_frame": int(rays_frame), "sharding": "row bands of %d, interleaved" % BAND_ROWS if world > 1 else "none"},
+        "ms_per_frame": round(ms_per_step, 4),
+    }
+
+    if rank == 0:
+        result["roofline"] = roofline(tracer, opt, W, H, dev, stream)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene, opt, ms_per_step)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline(tracer, opt, W, H, dev, stream):
+    """Dominant kernel of the frame: its algorithmic bytes per launch over its measured duration (HIP events recorded
+    by the library around the kernel, on the stream it runs on)."""
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    # bytes: one counted frame (kernels that also tally fetched nodes / tested triangles; not timed)
+    copt = Options.from_buffer_copy(opt)
+    copt.count_traversal = 1
+    _, cs = tracer.render_rect(copt, 0, 0, W, H, out=out, stats=True, stream=stream)
+    # time: a few plain frames with per-kernel events
+    ext, sha, shade = [], [], []
+    for _ in range(5):
+        _, st = tracer.render_rect(opt, 0, 0, W, H, out=out, stats=True, stream=stream)
+        ext.append(st.ms_extend); sha.append(st.ms_shadow); shade.append(st.ms_shade)
+    ms_ext, ms_sha, ms_shade = float(np.mean(ext)), float(np.mean(sha)), float(np.mean(shade))
+    # per ray: the node's queue records it reads/writes + 64 B per inner node fetched + 48 B per triangle tested
+    # (+ 36 B of vertex normals for a nearest hit); DESIGN.md "Kernels" states these figures
+    b_ext = cs.rays_closest * (48 + 28 + 36) + 64 * cs.nodes_extend + 48 * cs.tris_extend
+    b_sha = cs.rays_any * (16 + 4 + 16 + 16 + 16 + 4) + 64 * cs.nodes_shadow + 48 * cs.tris_shadow
+    if ms_sha >= ms_ext:
+        name, b, ms, rays, nn, nt = "k_shadow (any-hit light rays)", b_sha, ms_sha, cs.rays_any, cs.nodes_shadow, cs.tris_shadow
+    else:
+        name, b, ms, rays, nn, nt = "k_extend (nearest hit)", b_ext, ms_ext, cs.rays_closest, cs.nodes_extend, cs.tris_extend
+    achieved = b / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(name.split()[0])
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "launch_ms": round(ms, 4), "rays_per_launch": int(rays), "algorithmic_bytes_per_launch": int(b),
+            "nodes_per_ray": round(nn / max(rays, 1), 2), "tris_per_ray": round(nt / max(rays, 1), 2),
+            "ms_extend": round(ms_ext, 4), "ms_shadow": round(ms_sha, 4), "ms_replay": round(ms_shade, 4),
+            "note": "algorithmic bytes are mostly served by L2 (the tree is ~1 MB), so achieved may exceed HBM peak; "
+                    "traffic = measured HBM bytes per launch"}
+
+
+def cpu_baseline(scene, opt, gpu_ms):
+    """The CPU oracle (a port of the reference's loop, with the reference's fork/join tile partitioning) timed on this
+    box's host cores on the same frame."""
+    from oracle.oracle import OracleScene
+    cores = min(16, os.cpu_count() or 1)
+    o = OracleScene(scene)
+    # a bounded sample: the central 960x540 quarter of the frame's pixels would bias the hit rate, so rows are sampled
+    # instead: every 4th 100-row block is not possible with the reference's partitioning; render the whole frame at
+    # quarter resolution (same camera, same options), which keeps rays per pixel and the hit fraction
+    q = Options.from_buffer_copy(opt)
+    q.width, q.height = opt.width // 2, opt.height // 2
+    _, st, secs = o.render_frame_mt(q, cores)
+    rays = st.rays_closest + st.rays_any
+    return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "same scene and options at %dx%d (1/4 of the pixels), %d get_hit calls in %.1f s, reference "
+                      "renderFrame partitioning with %d hardware threads" % (q.width, q.height, rays, secs, cores),
+            "frame_seconds_extrapolated": round(secs * 4, 2), "gpu_frame_ms": round(gpu_ms, 3)}
+
+
+if __name__ == "__main__":
+    main()

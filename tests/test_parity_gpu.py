@@ -37,6 +37,12 @@ def test_trace_parity_random_rays(oracle_mod, name, exact):
     c = P.mean(0)
     ext = float(np.abs(P - c).max())
     org, d = random_rays(40000, 7, center=c, spread=3.0 * ext)
+    # aim half of the rays at points near the surface so that thin meshes are hit often too
+    rng = np.random.RandomState(3)
+    k = len(org) // 2
+    tgt = P[rng.randint(len(P), size=k)] + (rng.rand(k, 3) - 0.5) * 0.02 * ext
+    dd = tgt - org[-k:]
+    d[-k:] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
     t0 = 1e-4
     to, trio, nro = o.trace(org, d, t0, np.inf)
     tg, trig, nrg = g.trace(org, d, t0, np.inf, exact_boxes=bool(exact))
