@@ -175,17 +175,20 @@ def cpu_baseline(scene, opt, gpu_ms):
     from oracle.oracle import OracleScene
     cores = min(16, os.cpu_count() or 1)
     o = OracleScene(scene)
-    # a bounded sample: the central 960x540 quarter of the frame's pixels would bias the hit rate, so rows are sampled
-    # instead: every 4th 100-row block is not possible with the reference's partitioning; render the whole frame at
-    # quarter resolution (same camera, same options), which keeps rays per pixel and the hit fraction
-    q = Options.from_buffer_copy(opt)
-    q.width, q.height = opt.width // 2, opt.height // 2
-    _, st, secs = o.render_frame_mt(q, cores)
+    # the same frame, whole, twice; the faster run counts (shared host cores are noisy)
+    best = None
+    for _ in range(2):
+        _, st, secs = o.render_frame_mt(opt, cores)
+        if best is None or secs < best[1]:
+            best = (st, secs)
+    st, secs = best
     rays = st.rays_closest + st.rays_any
     return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "same scene and options at %dx%d (1/4 of the pixels), %d get_hit calls in %.1f s, reference "
-                      "renderFrame partitioning with %d hardware threads" % (q.width, q.height, rays, secs, cores),
-            "frame_seconds_extrapolated": round(secs * 4, 2), "gpu_frame_ms": round(gpu_ms, 3)}
+            "sample": "the whole %dx%d frame, best of 2 runs: %d get_hit calls (the reference traces every render ray "
+                      "twice) in %.2f s, reference renderFrame partitioning (100-pixel blocks, %d threads per block)"
+                      % (opt.width, opt.height, rays, secs, int(np.ceil(np.sqrt(cores))) ** 2),
+            "frame_seconds": round(secs, 3), "gpu_frame_ms": round(gpu_ms, 3),
+            "frame_time_ratio": round(secs * 1e3 / gpu_ms, 1)}
 
 
 if __name__ == "__main__":
