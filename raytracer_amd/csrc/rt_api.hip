@@ -315,11 +315,10 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         for (;;) {
             rt::Level& L = sc->lv[lvl].L;
             HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint32_t), s));
-            if (nl > 0) HIP_TRY(hipMemsetAsync(L.unocc, 0, (size_t)n * nl * sizeof(uint32_t), s));
             if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
             rt::launch_extend(exact, sc->d, P, L, n, sc->d_counters, counting ? (unsigned long long*)(sc->d_counters + 4) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
-            rt::launch_shadow(exact, sc->d, P, L, n * nl * (o->spr + 1), d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
+            rt::launch_shadow(exact, sc->d, P, L, n * nl, d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[2], s));
             HIP_TRY(hipMemcpyAsync(sc->h_counters, sc->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));

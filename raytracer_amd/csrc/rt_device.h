@@ -10,11 +10,15 @@
 #ifndef RT_HOST_EMULATION
 #include <hip/hip_runtime.h>
 #define RT_HD __device__ __forceinline__
+#define RT_HDM __device__ __forceinline__   // the same for member functions
 #define RT_CLZ(x) __clz(x)
 #define RT_F2I(x) __float_as_int(x)
 #define RT_I2F(x) __int_as_float(x)
 #define RT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define RT_ATOMIC_INC(p) atomicAdd((p), 1u)
+#define RT_RCP(x) __builtin_amdgcn_rcpf(x)
+// keeps all four lanes of a loaded float4 "used" so that the load stays one 16-byte instruction
+#define RT_KEEP4(q) asm volatile("" ::"v"((q).x), "v"((q).y), "v"((q).z), "v"((q).w))
 #endif
 
 namespace rt {
@@ -143,90 +147,131 @@ RT_HD bool slab(const float* b, V3 o, V3 d, V3 rd, float& tmin) {
 }
 
 #ifndef RT_STACK
-#define RT_STACK 96
+#define RT_STACK 96       // deepest tree the traversal accepts (checked when the scene is created)
 #endif
+#define RT_LDS_SLOTS 16   // stack entries per lane kept in LDS; deeper entries go to a per-lane array
+
+// Per-lane stack of postponed child references.  The first RT_LDS_SLOTS entries live in LDS, laid out
+// [slot][lane of the workgroup] so that a wave's access to one slot is conflict-free; the rest spill to private
+// memory.  Near-first descent rarely holds more than a handful of entries.
+struct StackLds {
+    int32_t* lds;            // this lane's column: slot s is lds[s * stride]
+    int stride;
+    int32_t spill[RT_STACK - RT_LDS_SLOTS];
+    int sp;
+    RT_HDM void push(int32_t v) {
+        if (sp < RT_LDS_SLOTS) lds[sp * stride] = v;
+        else if (sp < RT_STACK) spill[sp - RT_LDS_SLOTS] = v;
+        ++sp;
+    }
+    RT_HDM int32_t pop() {
+        --sp;
+        return (sp < RT_LDS_SLOTS) ? lds[sp * stride] : spill[sp - RT_LDS_SLOTS];
+    }
+};
+
+// One triangle against the ray: the reference's Cramer's-rule test (src/geometry.cpp:268-295, same names, same
+// operation order).  Its three true divisions are the expensive part, so each quotient is first estimated with
+// the hardware reciprocal (relative error of a few units in the last place): a triangle whose estimate is outside
+// the accepted range by far more than that error is rejected at once, everything else takes the exact division.
+// Returns true when the reference's test passes; t, beta, gamma are then the reference's values bit for bit.
+RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 d, float t0, float tlim,
+                    float& t_out, float& beta_out, float& gamma_out) {
+    const float a_ = p1.x, b_ = p1.y, c_ = p1.z;
+    const float d_ = p2.x, e_ = p2.y, f_ = p2.z;
+    const float g_ = d.x, h_ = d.y, i_ = d.z;
+    const float j_ = p0.x - o.x, k_ = p0.y - o.y, l_ = p0.z - o.z;
+    const float ei_hf = e_ * i_ - h_ * f_;
+    const float gf_di = g_ * f_ - d_ * i_;
+    const float dh_eg = d_ * h_ - e_ * g_;
+    const float ak_jb = a_ * k_ - j_ * b_;
+    const float jc_al = j_ * c_ - a_ * l_;
+    const float bl_kc = b_ * l_ - k_ * c_;
+    const float m = a_ * ei_hf + b_ * gf_di + c_ * dh_eg;
+    const float rm = RT_RCP(m);
+    const float tn = f_ * ak_jb + e_ * jc_al + d_ * bl_kc;
+    const float gn = i_ * ak_jb + h_ * jc_al + g_ * bl_kc;
+    const float bn = j_ * ei_hf + k_ * gf_di + l_ * dh_eg;
+    // estimates; a NaN estimate fails every comparison below and so falls through to the exact path
+    const float te = -(tn * rm), ge = gn * rm, be = bn * rm;
+    const float slack = 1e-4f;
+    if (te < t0 - slack * fabsf(t0) - 1e-30f || te > tlim + slack * fabsf(tlim)) return false;
+    if (ge < -slack || ge > 1.f + slack) return false;
+    if (be < -slack || be + ge > 1.f + 2.f * slack) return false;
+    const float t = tn / -m;
+    if (t < t0 || t > tlim) return false;
+    const float gamma = gn / m;
+    if (gamma < 0.f || gamma > 1.f) return false;
+    const float beta = bn / m;
+    if (beta < 0.f || beta > (1.f - gamma)) return false;
+    t_out = t; beta_out = beta; gamma_out = gamma;
+    return true;
+}
 
 // Nearest hit (ANY == false) or any hit (ANY == true) with t in [t0, t1].
 // Returns true on a hit.  Nearest: best = (t, position) minimal in (t, position) order, which is the reference's
 // choice among equal t (see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
 // reference's exhaustive recursion (src/geometry.cpp:155-187); otherwise subtrees whose entry distance exceeds the
 // best t so far are skipped and the nearer child is visited first.
+// Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
+// so that the lanes of a wave run the same kind of work together.
 template <bool ANY, bool EXACT>
-RT_HD bool traverse(const DScene& sc, V3 o, V3 d, float t0, float t1, HitRec& best,
-                                         uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
+                    uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     best.t = INFINITY; best.tri = -1; best.beta = 0.f; best.gamma = 0.f;
     V3 rd = v3(0, 0, 0);
     if (!EXACT) rd = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    int32_t stack[RT_STACK];
-    int sp = 0;
+    st.sp = 0;
     int32_t cur = 0;
     bool found = false;
     for (;;) {
-        if (cur >= 0) {
+        // ---- descend until a leaf is reached (cur < 0) or nothing is left (cur == RT_NONE)
+        while (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2); RT_KEEP4(q3);
             if (n_nodes) ++*n_nodes;
             const float lb[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
             const float rb[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
             const int32_t lref = RT_F2I(q3.x), rref = RT_F2I(q3.y);
             float tl, tr;
             bool hl = slab<EXACT>(lb, o, d, rd, tl);
-            bool hr = (rref != RT_NONE) && slab<EXACT>(rb, o, d, rd, tr);
+            bool hr = slab<EXACT>(rb, o, d, rd, tr) && (rref != RT_NONE);
             if (!EXACT) {
                 const float lim = ANY ? t1 : best.t;
                 hl = hl && !(tl > lim); hr = hr && !(tr > lim);
             }
             if (hl && hr) {
-                int32_t near_ = lref, far_ = rref;
-                if (!EXACT && tr < tl) { near_ = rref; far_ = lref; }
-                if (sp < RT_STACK) stack[sp++] = far_;
-                cur = near_;
-                continue;
-            }
-            if (hl) { cur = lref; continue; }
-            if (hr) { cur = rref; continue; }
-        } else {
-            int32_t k = ~cur;
-            int32_t run = 1;
-            do {
-                const float4* tp = reinterpret_cast<const float4*>(sc.tris + k);
-                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                if (n_tris) ++*n_tris;
-                if (k == ~cur) run = RT_F2I(p0.w);
-                // src/geometry.cpp:268-295 (Cramer's rule), same names
-                const float a_ = p1.x, b_ = p1.y, c_ = p1.z;
-                const float d_ = p2.x, e_ = p2.y, f_ = p2.z;
-                const float g_ = d.x, h_ = d.y, i_ = d.z;
-                const float j_ = p0.x - o.x, k_ = p0.y - o.y, l_ = p0.z - o.z;
-                const float ei_hf = e_ * i_ - h_ * f_;
-                const float gf_di = g_ * f_ - d_ * i_;
-                const float dh_eg = d_ * h_ - e_ * g_;
-                const float ak_jb = a_ * k_ - j_ * b_;
-                const float jc_al = j_ * c_ - a_ * l_;
-                const float bl_kc = b_ * l_ - k_ * c_;
-                const float m = a_ * ei_hf + b_ * gf_di + c_ * dh_eg;
-                const float t = (f_ * ak_jb + e_ * jc_al + d_ * bl_kc) / -m;
-                bool ok = !(t < t0 || t > t1);
-                if (!ANY) ok = ok && !(t > best.t);
-                if (ok) {
-                    const float gamma = (i_ * ak_jb + h_ * jc_al + g_ * bl_kc) / m;
-                    if (!(gamma < 0.f || gamma > 1.f)) {
-                        const float beta = (j_ * ei_hf + k_ * gf_di + l_ * dh_eg) / m;
-                        if (!(beta < 0.f || beta > (1.f - gamma))) {
-                            // a NaN t (0/0 on a zero-area triangle) passes every comparison above; it is never a hit here
-                            if (ANY) { if (t == t) return true; }
-                            else if (t < best.t || (t == best.t && k < best.tri)) {
-                                best.t = t; best.tri = k; best.beta = beta; best.gamma = gamma;
-                                found = true;
-                            }
-                        }
-                    }
-                }
-                ++k;
-            } while (--run > 0);
+                const bool swap = !EXACT && tr < tl;
+                st.push(swap ? lref : rref);
+                cur = swap ? rref : lref;
+            } else if (hl) cur = lref;
+            else if (hr) cur = rref;
+            else cur = st.sp ? st.pop() : RT_NONE;
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
+        if (cur == RT_NONE) break;
+        // ---- one leaf: a run of consecutive triangles
+        {
+            int32_t k = ~cur;
+            const float4* tp = reinterpret_cast<const float4*>(sc.tris + k);
+            int32_t run = 1;
+            for (int32_t r = 0; r < run; ++r, ++k, tp += 3) {
+                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                RT_KEEP4(p0); RT_KEEP4(p1); RT_KEEP4(p2);
+                if (r == 0) run = RT_F2I(p0.w);
+                if (n_tris) ++*n_tris;
+                float t, beta, gamma;
+                if (!tri_test(p0, p1, p2, o, d, t0, ANY ? t1 : fminf(t1, best.t), t, beta, gamma)) continue;
+                // a NaN t (0/0 on a zero-area triangle) passes every comparison of the test; it is never a hit here
+                if (ANY) { if (t == t) return true; }
+                else if (t < best.t || (t == best.t && k < best.tri)) {
+                    best.t = t; best.tri = k; best.beta = beta; best.gamma = gamma;
+                    found = true;
+                }
+            }
+        }
+        if (st.sp == 0) break;
+        cur = st.pop();
     }
     return found;
 }

@@ -29,7 +29,8 @@ struct Level {
     int32_t* tri;      // triangle position (traversal order) or -1
     int2* kids;        // x = first child in the next level (-1: none), y = number of children
     float* aux;        // Schlick term r_theta of a refractive spawn
-    uint32_t* unocc;   // [n][n_lights] light rays that reached the light, out of spr+1
+    uint32_t* unocc;   // [n][n_lights] light rays that reached the light, out of spr+1 (written only where the
+                       // node's companion shadow ray hit)
 };
 
 RT_HD int meta_type(int y) { return y & 0xff; }
@@ -77,11 +78,11 @@ RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
 
 // returns the number of children this node will spawn
 template <bool EXACT>
-RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, int64_t i,
+RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t i,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     const V3 o = f4v(L.org[i]), d = f4v(L.dir[i]);
     HitRec h;
-    const bool hit = traverse<false, EXACT>(sc, o, d, P.eps, INFINITY, h, n_nodes, n_tris);
+    const bool hit = traverse<false, EXACT>(sc, st, o, d, P.eps, INFINITY, h, n_nodes, n_tris);
     int2 kd; kd.x = -1; kd.y = 0;
     L.kids[i] = kd;
     if (!hit) {
@@ -106,25 +107,26 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, i
 }
 
 // ------------------------------------------------------------------------------------------------ shadow
-// w = (node * n_lights + light) * (spr + 1) + k.  Returns 1 if a ray was traced.
+// w = node * n_lights + light: the lane traces the spr jittered rays and the exact ray toward one light
+// (src/render_thread.cpp:146-161) and stores how many reached it.  Returns the number of rays traced.
 template <bool EXACT>
-RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, int64_t w,
+RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t w,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    const int per = P.spr + 1;
-    const int64_t nl = w / per;
-    const int k = (int)(w - nl * per);
-    const int64_t i = nl / sc.n_lights;
-    const int li = (int)(nl - i * sc.n_lights);
+    const int64_t i = w / sc.n_lights;
+    const int li = (int)(w - i * sc.n_lights);
     const int comp = L.meta[i].w;
     if (L.tri[comp] < 0) return 0;                                  // the shadow-type ray missed: record stays stale
     const V3 p = point_at(f4v(L.org[comp]), f4v(L.dir[comp]), L.hit[comp].w);
     const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
     const V3 exact = vnorm(light_dir(sc.lights[li], p, P, key, SITE_SH_LIGHT, (uint32_t)li));   // Ray ctor normalises
-    const V3 d = (k < P.spr) ? split_dir(exact, P.ray_eps, P, key, SITE_SH_SPLIT, (uint32_t)li, (uint32_t)k) : exact;
-    HitRec h;
-    const bool occluded = traverse<true, EXACT>(sc, p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris);
-    if (!occluded) RT_ATOMIC_INC(&L.unocc[i * sc.n_lights + li]);
-    return 1;
+    uint32_t unocc = 0;
+    for (int k = 0; k <= P.spr; ++k) {
+        const V3 d = (k < P.spr) ? split_dir(exact, P.ray_eps, P, key, SITE_SH_SPLIT, (uint32_t)li, (uint32_t)k) : exact;
+        HitRec h;
+        if (!traverse<true, EXACT>(sc, st, p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris)) ++unocc;
+    }
+    L.unocc[w] = unocc;
+    return P.spr + 1;
 }
 
 // ------------------------------------------------------------------------------------------------- spawn
@@ -328,11 +330,11 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
 // ------------------------------------------------------------------------------------------- batch trace
 template <bool ANY, bool EXACT>
 RT_HD void body_trace(const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t i,
-                      float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cnt_nodes, uint32_t* cnt_tris) {
+                      float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cnt_nodes, uint32_t* cnt_tris, StackLds& st) {
     const V3 o = v3p(org + 3 * i), d = v3p(dir + 3 * i);
     HitRec h;
     uint32_t nn = 0, nt = 0;
-    const bool hit = traverse<ANY, EXACT>(sc, o, d, t0, t1, h, cnt_nodes ? &nn : nullptr, cnt_tris ? &nt : nullptr);
+    const bool hit = traverse<ANY, EXACT>(sc, st, o, d, t0, t1, h, cnt_nodes ? &nn : nullptr, cnt_tris ? &nt : nullptr);
     if (ANY) {
         t_out[i] = hit ? 0.f : INFINITY;
         if (tri_out) tri_out[i] = hit ? 0 : -1;

@@ -6,6 +6,12 @@ namespace {
 
 constexpr int BLOCK = 256;
 
+// LDS part of the traversal stacks of one workgroup: [RT_LDS_SLOTS][BLOCK]
+#define RT_DECLARE_STACK(st)                                          \
+    __shared__ int32_t lds_stack_[RT_LDS_SLOTS * BLOCK];              \
+    StackLds st;                                                      \
+    st.lds = lds_stack_ + threadIdx.x; st.stride = BLOCK; st.sp = 0
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -29,7 +35,8 @@ template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     uint32_t kids = 0, nn = 0, nt = 0;
-    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    RT_DECLARE_STACK(st);
+    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     kids = wave_sum(kids);
     if ((threadIdx.x & 63) == 0 && kids) atomicAdd(&counters[0], kids);
     add_work<COUNT>(work, nn, nt);
@@ -39,7 +46,8 @@ template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, unsigned long long* traced, unsigned long long* work) {
     const int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     uint32_t did = 0, nn = 0, nt = 0;
-    if (w < n_items) did = (uint32_t)body_shadow<EXACT>(sc, P, L, w, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    RT_DECLARE_STACK(st);
+    if (w < n_items) did = (uint32_t)body_shadow<EXACT>(sc, P, L, st, w, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     did = wave_sum(did);
     if ((threadIdx.x & 63) == 0 && did) atomicAdd(traced, (unsigned long long)did);
     add_work<COUNT>(work, nn, nt);
@@ -59,7 +67,8 @@ template <bool ANY, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float* org, const float* dir, float t0, float t1, int64_t n,
                                                  float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) body_trace<ANY, EXACT>(sc, org, dir, t0, t1, i, t_out, tri_out, nrm_out, cn, ct);
+    RT_DECLARE_STACK(st);
+    if (i < n) body_trace<ANY, EXACT>(sc, org, dir, t0, t1, i, t_out, tri_out, nrm_out, cn, ct, st);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_resolve_u8(const float* rgb, int W, int H, int64_t n, uint8_t* out) {

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Hardware-counter passes over the bench (one rocprofv3 run per pass; counters are never mixed with tracing).
+# usage: tools/pmc_profile.sh <out_dir_under_gpurun_out> [workload]
+set -o pipefail
+R="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$R/gpurun_out/$1"; WL="${2:-bunny_lambert_1080p}"
+mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
+PASSES=(
+ "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+ "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
+)
+i=0
+for p in "${PASSES[@]}"; do
+  timeout -s KILL 120 rocprofv3 --pmc $p --output-format csv -d "$OUT/pass$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --workload "$WL" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; exit 1; }
+  i=$((i+1))
+done
+python3 "$R/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt"; cat "$OUT/summary.txt"
