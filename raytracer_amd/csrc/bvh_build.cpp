@@ -7,10 +7,13 @@
 //   * a node's box is stored in its parent (both children's boxes in one 64-byte record);
 //   * the bottom nodes of the reference (a node holding one triangle, two triangles, or a TriangleSet)
 //     become leaves: a run of consecutive triangles plus the box the reference tests before them;
-//   * triangles are emitted in "tie order": wherever the reference prefers one candidate on equal t
-//     (right child over left, src/geometry.cpp:171-175; lower index inside a set, :428; earlier mesh,
-//     src/render_thread.cpp:15) that candidate gets the lower position, so "lowest position wins ties"
-//     reproduces its choice under any traversal order;
+//   * every triangle gets a tie rank: wherever the reference prefers one candidate on equal t (right child
+//     over left, src/geometry.cpp:171-175; lower index inside a set, :428; earlier mesh,
+//     src/render_thread.cpp:15) that candidate gets the lower rank, so "lowest rank wins ties" reproduces its
+//     choice under any traversal order;
+//   * a second pair of child references per node ("fine") replaces leaves of more than RT_FINE_LEAF triangles
+//     by a median-split subtree over the leaf's triangles; it changes which boxes are tested, never the answer
+//     (ties are decided by rank), and is what the pruning traversal uses;
 //   * the meshes' roots hang under a small top tree over mesh boxes instead of being looped over
 //     (src/render_thread.cpp:10); a parent box is the exact union of its children, so it never fails
 //     where a descendant passes.
@@ -33,13 +36,22 @@ inline void box_union(Box& a, const Box& b) {                 // src/geometry.cp
     for (int i = 0; i < 3; ++i) { a.lo[i] = fminf(a.lo[i], b.lo[i]); a.hi[i] = fmaxf(a.hi[i], b.hi[i]); }
 }
 
-struct Built { int32_t ref; Box box; int depth; };
+struct Built { int32_t ref, ref_fine; Box box; int depth; };
+
+constexpr int RT_FINE_LEAF = 4;
+
+inline void set_node(Node64& n, const Built& L, const Built& R) {
+    memcpy(n.lbox, L.box.lo, 12); memcpy(n.lbox + 3, L.box.hi, 12);
+    memcpy(n.rbox, R.box.lo, 12); memcpy(n.rbox + 3, R.box.hi, 12);
+    n.lref = L.ref; n.rref = R.ref; n.lref_fine = L.ref_fine; n.rref_fine = R.ref_fine;
+}
 
 struct Builder {
     const float* pos;      // current mesh: [n][3][3]
     const float* nrm;
     int mesh_index;
     int id_base;           // global id of the mesh's first triangle
+    int rank_base;         // rank of the mesh's most preferred triangle (earlier meshes rank lower)
     std::vector<Box> tbox; // per triangle of the current mesh
     FlatScene* out;
 
@@ -53,21 +65,73 @@ struct Builder {
         return r;
     }
 
+    int next_rank = 0;     // ranks follow the reference's preference order (this builder's emission order)
+
+    void emit(int t, int run, int run_fine, int rank) {
+        const float* a = pos + (size_t)t * 9; const float* b = a + 3; const float* c = a + 6;
+        Tri48 q;
+        q.ax = a[0]; q.ay = a[1]; q.az = a[2]; q.run = run;
+        q.abx = a[0] - b[0]; q.aby = a[1] - b[1]; q.abz = a[2] - b[2]; q.run_fine = run_fine;
+        q.acx = a[0] - c[0]; q.acy = a[1] - c[1]; q.acz = a[2] - c[2]; q.rank = rank;
+        out->tris.push_back(q);
+        TriInfo fi; fi.id = id_base + t; fi.mesh = mesh_index;
+        out->info.push_back(fi);
+        const float* nn = nrm + (size_t)t * 9;
+        out->nrm.insert(out->nrm.end(), nn, nn + 9);
+    }
+
+    struct Ranked { int t, rank; };
+
+    // Subtree over the triangles of one big leaf: median split of box centres along the widest axis.
+    // `left` = triangles of the whole leaf still to be emitted after this group (for the coarse run lengths).
+    Built refine(Ranked* v, int n, int left) {
+        Built r; r.depth = 0;
+        r.box = tbox[v[0].t];
+        for (int k = 1; k < n; ++k) box_union(r.box, tbox[v[k].t]);
+        if (n <= RT_FINE_LEAF) {
+            r.ref = r.ref_fine = ~(int32_t)out->tris.size();
+            for (int k = 0; k < n; ++k) emit(v[k].t, left + n - k, n - k, v[k].rank);
+            return r;
+        }
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < 3; ++i) {
+                const float c = tbox[v[k].t].lo[i] + tbox[v[k].t].hi[i];
+                cmin[i] = fminf(cmin[i], c); cmax[i] = fmaxf(cmax[i], c);
+            }
+        int ax = 0;
+        for (int i = 1; i < 3; ++i) if (cmax[i] - cmin[i] > cmax[ax] - cmin[ax]) ax = i;
+        const int mid = n / 2;
+        std::nth_element(v, v + mid, v + n, [&](const Ranked& x, const Ranked& y) {
+            const float cx = tbox[x.t].lo[ax] + tbox[x.t].hi[ax], cy = tbox[y.t].lo[ax] + tbox[y.t].hi[ax];
+            return cx < cy || (cx == cy && x.rank < y.rank);
+        });
+        const int32_t idx = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        const Built L = refine(v, mid, left + (n - mid));
+        const Built R = refine(v + mid, n - mid, left);
+        Built Lf = L, Rf = R;                      // inside the subtree both reference pairs are the fine ones
+        Lf.ref = L.ref_fine; Rf.ref = R.ref_fine;
+        set_node(out->nodes[idx], Lf, Rf);
+        r.ref = r.ref_fine = idx;
+        r.depth = 1 + std::max(L.depth, R.depth);
+        return r;
+    }
+
     Built leaf(const int* ids, int n) {
         Built r; r.depth = 0;
-        r.ref = ~(int32_t)out->tris.size();
         r.box = tbox[ids[0]];
-        for (int k = 0; k < n; ++k) {
-            const int t = ids[k];
-            box_union(r.box, tbox[t]);
-            const float* a = pos + (size_t)t * 9; const float* b = a + 3; const float* c = a + 6;
-            Tri48 q;
-            q.ax = a[0]; q.ay = a[1]; q.az = a[2]; q.run = n - k;
-            q.abx = a[0] - b[0]; q.aby = a[1] - b[1]; q.abz = a[2] - b[2]; q.id = id_base + t;
-            q.acx = a[0] - c[0]; q.acy = a[1] - c[1]; q.acz = a[2] - c[2]; q.mesh = mesh_index;
-            out->tris.push_back(q);
-            const float* nn = nrm + (size_t)t * 9;
-            out->nrm.insert(out->nrm.end(), nn, nn + 9);
+        for (int k = 0; k < n; ++k) box_union(r.box, tbox[ids[k]]);
+        r.ref = ~(int32_t)out->tris.size();
+        std::vector<Ranked> v(n);
+        for (int k = 0; k < n; ++k) { v[k].t = ids[k]; v[k].rank = rank_base + next_rank++; }
+        if (n <= RT_FINE_LEAF) {
+            r.ref_fine = r.ref;
+            for (int k = 0; k < n; ++k) emit(v[k].t, n - k, n - k, v[k].rank);
+        } else {
+            const Built f = refine(v.data(), n, 0);
+            r.ref_fine = f.ref_fine;
+            r.depth = f.depth;
         }
         out->n_leaves++;
         return r;
@@ -105,11 +169,8 @@ struct Builder {
         out->nodes.emplace_back();
         const Built R = build(rl, (axis + 1) % 3, depth - 1);                  // right first: lower tie positions
         const Built L = build(ll, (axis + 1) % 3, depth - 1);
-        Node64& n = out->nodes[idx];
-        memcpy(n.lbox, L.box.lo, 12); memcpy(n.lbox + 3, L.box.hi, 12);
-        memcpy(n.rbox, R.box.lo, 12); memcpy(n.rbox + 3, R.box.hi, 12);
-        n.lref = L.ref; n.rref = R.ref; n.pad[0] = n.pad[1] = 0;
-        Built r; r.ref = idx; r.box = L.box; box_union(r.box, R.box);
+        set_node(out->nodes[idx], L, R);
+        Built r; r.ref = r.ref_fine = idx; r.box = L.box; box_union(r.box, R.box);
         r.depth = 1 + std::max(L.depth, R.depth);
         return r;
     }
@@ -134,11 +195,8 @@ Built build_top(FlatScene* out, std::vector<Built>& roots, int lo, int hi) {
     out->nodes.emplace_back();
     const Built L = build_top(out, roots, lo, mid);
     const Built R = build_top(out, roots, mid, hi);
-    Node64& n = out->nodes[idx];
-    memcpy(n.lbox, L.box.lo, 12); memcpy(n.lbox + 3, L.box.hi, 12);
-    memcpy(n.rbox, R.box.lo, 12); memcpy(n.rbox + 3, R.box.hi, 12);
-    n.lref = L.ref; n.rref = R.ref; n.pad[0] = n.pad[1] = 0;
-    Built r; r.ref = idx; r.box = L.box; box_union(r.box, R.box);
+    set_node(out->nodes[idx], L, R);
+    Built r; r.ref = r.ref_fine = idx; r.box = L.box; box_union(r.box, R.box);
     r.depth = 1 + std::max(L.depth, R.depth);
     return r;
 }
@@ -146,7 +204,7 @@ Built build_top(FlatScene* out, std::vector<Built>& roots, int lo, int hi) {
 }  // namespace
 
 bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, std::string* err) {
-    out->nodes.clear(); out->tris.clear(); out->nrm.clear();
+    out->nodes.clear(); out->tris.clear(); out->info.clear(); out->nrm.clear();
     out->n_leaves = 0; out->max_depth = 0;
     out->nodes.emplace_back();                       // node 0 = entry, filled in last
     std::vector<Built> roots;
@@ -156,7 +214,7 @@ bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, 
         if (md.n_tris < 0 || (md.n_tris > 0 && (!md.pos || !md.nrm))) { *err = "mesh with null arrays or negative size"; return false; }
         if (md.n_tris == 0) continue;
         Builder b;
-        b.pos = md.pos; b.nrm = md.nrm; b.mesh_index = mi; b.id_base = id_base; b.out = out;
+        b.pos = md.pos; b.nrm = md.nrm; b.mesh_index = mi; b.id_base = id_base; b.rank_base = id_base; b.out = out;
         b.tbox.resize(md.n_tris);
         std::vector<int> ids(md.n_tris);
         for (int k = 0; k < md.n_tris; ++k) { b.tbox[k] = b.tri_box(k); ids[k] = k; }
@@ -170,6 +228,7 @@ bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, 
     if (roots.size() == 1) {
         memcpy(entry.lbox, roots[0].box.lo, 12); memcpy(entry.lbox + 3, roots[0].box.hi, 12);
         entry.lref = roots[0].ref; entry.rref = RT_NONE;
+        entry.lref_fine = roots[0].ref_fine; entry.rref_fine = RT_NONE;
         depth = 1 + roots[0].depth;
     } else {
         const Built top = build_top(out, roots, 0, (int)roots.size());

@@ -9,7 +9,8 @@ namespace rt {
 
 struct FlatScene {
     std::vector<Node64> nodes;   // nodes[0] is the entry node
-    std::vector<Tri48> tris;     // traversal ("tie") order
+    std::vector<Tri48> tris;     // traversal order (the reference's leaves stay contiguous)
+    std::vector<TriInfo> info;   // same order
     std::vector<float> nrm;      // [n_tris][3][3] vertex normals, same order as tris
     int n_leaves = 0;
     int max_depth = 0;           // longest chain of inner nodes from the entry to a leaf

@@ -159,6 +159,7 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     for (int i = 0; i < n_meshes; ++i) mesh_mat[i] = meshes[i].material;
     if ((rc = upload(sc, flat.nodes.data(), flat.nodes.size(), &sc->d.nodes)) != RT_OK ||
         (rc = upload(sc, flat.tris.data(), flat.tris.size(), &sc->d.tris)) != RT_OK ||
+        (rc = upload(sc, flat.info.data(), flat.info.size(), &sc->d.info)) != RT_OK ||
         (rc = upload(sc, flat.nrm.data(), flat.nrm.size(), &sc->d.nrm)) != RT_OK ||
         (rc = upload(sc, mats.data(), mats.size(), &sc->d.mats)) != RT_OK ||
         (rc = upload(sc, mesh_mat.data(), mesh_mat.size(), &sc->d.mesh_mat)) != RT_OK) {

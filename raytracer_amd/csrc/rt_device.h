@@ -26,6 +26,7 @@ namespace rt {
 struct DScene {
     const Node64* nodes;
     const Tri48* tris;
+    const TriInfo* info;       // per triangle, same order: caller's id and mesh index
     const float* nrm;          // [n_tris][9], traversal order
     const Material* mats;      // per material
     const int32_t* mesh_mat;   // mesh index -> material index
@@ -122,7 +123,7 @@ RT_HD V3 split_dir(V3 exact, float eps, const RenderParams& P, uint32_t node, ui
 }
 
 // ---- traversal ---------------------------------------------------------------------------------------------
-struct HitRec { float t; int32_t tri; float beta, gamma; };   // tri = position in traversal order, -1 = none
+struct HitRec { float t; int32_t tri; int32_t rank; float beta, gamma; };   // tri = position in the triangle array, -1 = none
 
 // Slab test of one box.  EXACT: the reference's arithmetic (src/geometry.cpp:25-37: six true divisions, fmin/fmax
 // that drop NaNs).  Otherwise a multiplication by the precomputed reciprocal replaces each division; tmin is
@@ -209,8 +210,8 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
 }
 
 // Nearest hit (ANY == false) or any hit (ANY == true) with t in [t0, t1].
-// Returns true on a hit.  Nearest: best = (t, position) minimal in (t, position) order, which is the reference's
-// choice among equal t (see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
+// Returns true on a hit.  Nearest: best = the candidate minimal in (t, tie rank) order, which is the reference's
+// choice among equal t (ranks: see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
 // reference's exhaustive recursion (src/geometry.cpp:155-187); otherwise subtrees whose entry distance exceeds the
 // best t so far are skipped and the nearer child is visited first.
 // Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
@@ -218,7 +219,7 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
 template <bool ANY, bool EXACT>
 RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
                     uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    best.t = INFINITY; best.tri = -1; best.beta = 0.f; best.gamma = 0.f;
+    best.t = INFINITY; best.tri = -1; best.rank = INT32_MAX; best.beta = 0.f; best.gamma = 0.f;
     V3 rd = v3(0, 0, 0);
     if (!EXACT) rd = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
     st.sp = 0;
@@ -233,7 +234,8 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
             if (n_nodes) ++*n_nodes;
             const float lb[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
             const float rb[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-            const int32_t lref = RT_F2I(q3.x), rref = RT_F2I(q3.y);
+            // the reference's own leaves when its exact box tests are asked for, the refined ones otherwise
+            const int32_t lref = RT_F2I(EXACT ? q3.x : q3.z), rref = RT_F2I(EXACT ? q3.y : q3.w);
             float tl, tr;
             bool hl = slab<EXACT>(lb, o, d, rd, tl);
             bool hr = slab<EXACT>(rb, o, d, rd, tr) && (rref != RT_NONE);
@@ -258,14 +260,14 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
             for (int32_t r = 0; r < run; ++r, ++k, tp += 3) {
                 const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
                 RT_KEEP4(p0); RT_KEEP4(p1); RT_KEEP4(p2);
-                if (r == 0) run = RT_F2I(p0.w);
+                if (r == 0) run = RT_F2I(EXACT ? p0.w : p1.w);
                 if (n_tris) ++*n_tris;
                 float t, beta, gamma;
                 if (!tri_test(p0, p1, p2, o, d, t0, ANY ? t1 : fminf(t1, best.t), t, beta, gamma)) continue;
                 // a NaN t (0/0 on a zero-area triangle) passes every comparison of the test; it is never a hit here
                 if (ANY) { if (t == t) return true; }
-                else if (t < best.t || (t == best.t && k < best.tri)) {
-                    best.t = t; best.tri = k; best.beta = beta; best.gamma = gamma;
+                else if (t < best.t || (t == best.t && RT_F2I(p2.w) < best.rank)) {
+                    best.t = t; best.tri = k; best.rank = RT_F2I(p2.w); best.beta = beta; best.gamma = gamma;
                     found = true;
                 }
             }

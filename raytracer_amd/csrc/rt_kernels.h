@@ -93,7 +93,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     const V3 n = hit_normal(sc, h);
     L.hit[i] = mk4(n, h.t);
     L.tri[i] = h.tri;
-    const Material& M = sc.mats[sc.mesh_mat[sc.tris[h.tri].mesh]];
+    const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
     const int4 m = L.meta[i];
     const int depth = meta_depth(m.y);
     if (depth > 0 && M.kind == 2) return P.spr + 1;
@@ -135,7 +135,7 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
     if (tri < 0) return;
     const int4 m = L.meta[i];
     const int depth = meta_depth(m.y);
-    const Material& M = sc.mats[sc.mesh_mat[sc.tris[tri].mesh]];
+    const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
     if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
     const V3 o = f4v(L.org[i]), d = f4v(L.dir[i]);
     const float4 hn = L.hit[i];
@@ -262,7 +262,7 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
             bool draw = false, has_kids = false;
             V3 c = v3(0, 0, 0);
             if (tri >= 0) {
-                const Material& M = sc.mats[sc.mesh_mat[sc.tris[tri].mesh]];
+                const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
                 const float4 hn = L.hit[i];
                 const V3 n = f4v(hn);
                 const V3 p = point_at(f4v(L.org[i]), f4v(L.dir[i]), hn.w);
@@ -340,7 +340,7 @@ RT_HD void body_trace(const DScene& sc, const float* org, const float* dir, floa
         if (tri_out) tri_out[i] = hit ? 0 : -1;
     } else {
         t_out[i] = hit ? h.t : INFINITY;
-        if (tri_out) tri_out[i] = hit ? sc.tris[h.tri].id : -1;
+        if (tri_out) tri_out[i] = hit ? sc.info[h.tri].id : -1;
         if (nrm_out) {
             const V3 n = hit ? hit_normal(sc, h) : v3(0, 0, 0);
             nrm_out[3 * i] = n.x; nrm_out[3 * i + 1] = n.y; nrm_out[3 * i + 2] = n.z;

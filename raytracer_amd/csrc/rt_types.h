@@ -11,21 +11,28 @@ static const int32_t RT_NONE = INT32_MIN;
 // 64-byte inner node: the boxes of BOTH children live in the parent, so one fetch decides both.
 // The reference stores a node's own box in the node (src/geometry.h:41-45); a child's box test there
 // (src/geometry.cpp:157) is this parent's test of the matching half here.
+// Two pairs of child references share the boxes: lref/rref describe the reference's tree exactly (its bottom
+// nodes are leaves, however many triangles they hold); lref_fine/rref_fine are the same except that a leaf with
+// more than a few triangles is replaced by a small subtree over that leaf's triangles (appended nodes).
 struct alignas(16) Node64 {
     float lbox[6];   // left child: lo.xyz, hi.xyz
     float rbox[6];   // right child
     int32_t lref;
     int32_t rref;
-    int32_t pad[2];
+    int32_t lref_fine;
+    int32_t rref_fine;
 };
 
 // 48-byte triangle, traversal order.  Edges are stored pre-subtracted exactly as Triangle::hit forms them
 // (src/geometry.cpp:268-273: a-b and a-c component-wise), so the device arithmetic is the same rounding sequence.
 struct alignas(16) Tri48 {
-    float ax, ay, az;  int32_t run;      // vertex a; run = triangles from this one to the end of its leaf
-    float abx, aby, abz; int32_t id;     // a - b; id = caller's global triangle id (mesh order, then face order)
-    float acx, acy, acz; int32_t mesh;   // a - c; mesh index
+    float ax, ay, az;  int32_t run;        // vertex a; run = triangles from this one to the end of the reference's leaf
+    float abx, aby, abz; int32_t run_fine; // a - b; the same for the refined leaves
+    float acx, acy, acz; int32_t rank;     // a - c; tie rank: among equal t the reference returns the lowest rank
 };
+
+// Per triangle (same order as Tri48), read only for the final hit.
+struct TriInfo { int32_t id; int32_t mesh; };   // caller's global triangle id (mesh order, then face order); mesh index
 
 struct Material {
     int32_t kind;
