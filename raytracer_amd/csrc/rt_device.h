@@ -19,6 +19,27 @@
 #define RT_RCP(x) __builtin_amdgcn_rcpf(x)
 // keeps all four lanes of a loaded float4 "used" so that the load stays one 16-byte instruction
 #define RT_KEEP4(q) asm volatile("" ::"v"((q).x), "v"((q).y), "v"((q).z), "v"((q).w))
+
+// Fetch of one 64-byte node.  When every active lane of the wave is at the same node (rays that are still together
+// near the top of the tree) the node is read ONCE through the scalar cache into SGPRs instead of by four 16-byte
+// vector loads per lane: the vector memory pipeline is the busiest unit of the traversal kernels and a wave-wide
+// vector load costs it the same whether the lanes ask for one node or for 64.
+typedef float rt_f16 __attribute__((ext_vector_type(16)));
+#define RT_LOAD_NODE(nodes, cur, q0, q1, q2, q3)                                                            \
+    do {                                                                                                     \
+        const int ucur_ = __builtin_amdgcn_readfirstlane(cur);                                               \
+        if (__builtin_amdgcn_ballot_w64((cur) != ucur_) == 0) {                                              \
+            rt_f16 s_;                                                                                       \
+            const void* up_ = (const void*)((nodes) + ucur_);                                                \
+            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) : "s"(up_) : "memory"); \
+            q0 = make_float4(s_[0], s_[1], s_[2], s_[3]); q1 = make_float4(s_[4], s_[5], s_[6], s_[7]);      \
+            q2 = make_float4(s_[8], s_[9], s_[10], s_[11]); q3 = make_float4(s_[12], s_[13], s_[14], s_[15]); \
+        } else {                                                                                             \
+            const float4* np_ = reinterpret_cast<const float4*>((nodes) + (cur));                            \
+            q0 = np_[0]; q1 = np_[1]; q2 = np_[2]; q3 = np_[3];                                              \
+            RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2); RT_KEEP4(q3);                                          \
+        }                                                                                                    \
+    } while (0)
 #endif
 
 namespace rt {
@@ -228,9 +249,8 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
     for (;;) {
         // ---- descend until a leaf is reached (cur < 0) or nothing is left (cur == RT_NONE)
         while (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2); RT_KEEP4(q3);
+            float4 q0, q1, q2, q3;
+            RT_LOAD_NODE(sc.nodes, cur, q0, q1, q2, q3);
             if (n_nodes) ++*n_nodes;
             const float lb[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
             const float rb[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
