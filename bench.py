@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 from raytracer_amd import api, scenes  # noqa: E402
 from raytracer_amd._abi import Options, RT_JITTER_HASH  # noqa: E402
-from raytracer_amd.distributed import band_schedule, gather_frame, render_local_bands  # noqa: E402
+from raytracer_amd.distributed import FrameGather, local_to_image_rows, run_pipelined  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, datasheet
 BAND_ROWS = 8
@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="bunny_lambert_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="check that the gathered frame is bit-equal to the same frame rendered whole on this rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -57,8 +59,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RT_BENCH_BACKEND=gloo lets several ranks rehearse the sharded path on ONE GPU (RCCL refuses that)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group(os.environ.get("RT_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -70,33 +73,38 @@ def main():
     W, H = opt.width, opt.height
     tracer = api.TracerScene(scene)
     stream = torch.cuda.current_stream().cuda_stream
-    bands = band_schedule(H, world, BAND_ROWS)[rank] if world > 1 else [(0, H)]
+    # this rank's share: every world-th band of BAND_ROWS rows, rendered by ONE call per frame
+    n_local = len(local_to_image_rows(H, world, rank, BAND_ROWS)) if world > 1 else H
+    if world > 1:
+        opt.row_stride, opt.row_band, opt.row_phase = world, BAND_ROWS, rank
+    gather = FrameGather(H, W, world, BAND_ROWS, dev) if world > 1 else None
+    # two sets of buffers: the gather of frame k overlaps the rendering of frame k+1
+    locals_ = [gather.new_local() if gather else torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    stacks = [gather.new_stack() if gather else None for _ in range(2)]
 
-    def render_rect(x0, y0, x1, y1, out, stats=False):
-        return tracer.render_rect(opt, x0, y0, x1, y1, out=out, stats=stats, stream=stream)[1]
+    def render(k, stats=False):
+        return tracer.render_rect(opt, 0, 0, W, n_local, out=locals_[k % 2][:n_local], stats=stats, stream=stream)[1]
 
-    def step():
-        local = render_local_bands(render_rect, bands, W, dev)
-        return gather_frame(local, H, W, world, BAND_ROWS) if world > 1 else local
-
-    # rays per frame on this rank (the same every step: the seed is fixed)
-    rays_local = 0
-    for y0, y1 in bands:
-        st = render_rect(0, y0, W, y1, torch.empty((y1 - y0, W, 3), dtype=torch.float32, device=dev), stats=True)
-        rays_local += st.rays_closest + st.rays_any
-    rays = torch.tensor([float(rays_local)], dtype=torch.float64, device=dev)
+    # rays per frame (the same every step: the seed is fixed)
+    st = render(0, stats=True)
+    rays = torch.tensor([float(st.rays_closest + st.rays_any)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(rays)
     rays_frame = float(rays.item())
 
-    for _ in range(args.warmup):
-        step()
+    def run(steps):
+        if not gather:
+            for k in range(steps):
+                render(k)
+            return locals_[(steps - 1) % 2]
+        return run_pipelined(steps, lambda k, buf: render(k), gather, locals_, stacks)
+
+    run(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame = step()
+    frame = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -107,6 +115,15 @@ def main():
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     value = rays_frame / (dt / args.steps) / 1e6
+    if gather:       # restore whole-frame options for the single-GPU profiling legs below
+        opt.row_stride, opt.row_band, opt.row_phase = 0, 0, 0
+    if args.verify:
+        whole = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        tracer.render_rect(opt, 0, 0, W, H, out=whole, stats=False, stream=stream)
+        torch.cuda.synchronize()
+        same = (whole.view(torch.int32) == frame.view(torch.int32)) | (torch.isnan(whole) & torch.isnan(frame))
+        if not bool(same.all()):
+            raise SystemExit("rank %d: gathered frame differs from the whole frame in %d values" % (rank, int((~same).sum())))
 
     result = {
         "metric": "Mrays/s (primary+secondary), whole 1080p 4spp frame through the hot path",
@@ -116,7 +133,8 @@ def main():
                                 "counter-hash jitter seed 1",
         "config": {"workload": args.workload, "width": W, "height": H, "spp": opt.spp * opt.spp, "spr": opt.spr + 1,
                    "max_bounce": opt.max_bounce, "triangles": scene.n_tris, "lights": len(scene.lights),
-                   "rays_per_frame": int(rays_frame), "sharding": "row bands of %d, interleaved" % BAND_ROWS if world > 1 else "none"},
+                   "rays_per_frame": int(rays_frame), "sharding": ("%d-row bands interleaved over ranks, one all_gather per frame overlapped with the next frame"
+                                % BAND_ROWS) if world > 1 else "none"},
         "ms_per_frame": round(ms_per_step, 4),
     }
 

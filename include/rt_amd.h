@@ -102,7 +102,11 @@ typedef struct rt_options {
                                       the triangles the reference visits; 0: reciprocal multiply + pruning */
     int32_t count_traversal;    /* 1: also count inner nodes fetched and triangles tested per kernel kind into
                                    rt_stats (slower kernels; for traffic accounting, not for timing) */
-    int32_t reserved_[3];
+    int32_t row_stride;         /* 0 or 1: rows are image rows.  N > 1: the rows given to rt_render_rect are LOCAL rows of
+                                   one of N interleaved shares of the image: local row l is image row
+                                   ((l / row_band) * N + row_phase) * row_band + l % row_band  (multi-GPU row bands) */
+    int32_t row_band;           /* band height of the interleave (>= 1 when row_stride > 1) */
+    int32_t row_phase;          /* which share, 0 .. row_stride-1 */
 } rt_options;
 
 typedef struct rt_stats {
@@ -159,7 +163,8 @@ int rt_trace_counted(rt_scene* scene, const float* org, const float* dir, float 
 
 /* Replaces RenderThread::operator()(Rasterizer*, AABBTree&, Camera*, std::vector<Light*>, int startX,
  * int startY, int endX, int endY, ...) (src/render_thread.h:22-25, src/render_thread.cpp:25-488).
- * Renders pixels x in [x0,x1), y in [y0,y1) (y = 0 is the bottom row, as in the reference) and writes
+ * Renders pixels x in [x0,x1), y in [y0,y1) (y = 0 is the bottom row, as in the reference; with
+ * rt_options.row_stride > 1 y counts the local rows of one interleaved share, see there) and writes
  * float RGB = sum(colours)/sum(weights) per pixel (src/rasterizer.cpp:88-103; no draw -> NaN) into
  * rgb_out[(y - y0) * (x1 - x0) + (x - x0)][3], host or device.  stats may be NULL. */
 int rt_render_rect(rt_scene* scene, const rt_options* opt, int x0, int y0, int x1, int y1,

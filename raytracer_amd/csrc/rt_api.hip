@@ -254,8 +254,17 @@ int rt_trace_counted(rt_scene* sc, const float* org, const float* dir, float t0,
 
 int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
     if (!sc || !o || !rgb_out) return fail(RT_ERR_INVALID, "rt_render_rect: null argument");
-    if (o->width <= 0 || o->height <= 0 || x0 < 0 || y0 < 0 || x1 > o->width || y1 > o->height || x0 > x1 || y0 > y1)
+    if (o->width <= 0 || o->height <= 0 || x0 < 0 || y0 < 0 || x1 > o->width || x0 > x1 || y0 > y1)
         return fail(RT_ERR_INVALID, "rt_render_rect: rectangle outside the image");
+    if (o->row_stride > 1) {
+        if (o->row_band < 1 || o->row_phase < 0 || o->row_phase >= o->row_stride)
+            return fail(RT_ERR_INVALID, "rt_render_rect: bad row interleave (row_band >= 1, 0 <= row_phase < row_stride)");
+        if (y1 > y0) {      // the last local row must map inside the image
+            const int l = y1 - 1;
+            if (((l / o->row_band) * o->row_stride + o->row_phase) * o->row_band + l % o->row_band >= o->height)
+                return fail(RT_ERR_INVALID, "rt_render_rect: local rows reach past the image");
+        }
+    } else if (y1 > o->height) return fail(RT_ERR_INVALID, "rt_render_rect: rectangle outside the image");
     if (o->spp < 1 || o->spp > 16 || o->spr < 0 || o->spr > 15 || o->max_bounce < 0 || o->max_bounce > 8 ||
         o->max_refrac_bounce < 0 || o->max_refrac_bounce > 8)
         return fail(RT_ERR_UNSUPPORTED, "rt_render_rect: spp 1..16, spr 0..15, bounce and rbounce 0..8");
@@ -271,6 +280,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     P.W = o->width; P.H = o->height; P.x0 = x0; P.y0 = y0; P.rw = rw; P.rh = rh;
     P.spp = o->spp; P.spr = o->spr; P.D = o->max_bounce; P.Dr = o->max_refrac_bounce;
     P.eps = o->eps; P.ray_eps = o->ray_eps; P.jitter = o->jitter_mode; P.seed = o->seed;
+    P.row_stride = o->row_stride; P.row_band = o->row_band; P.row_phase = o->row_phase;
     {   // src/render_thread.cpp:34-40 (PI is the float 3.1415926, :3)
         const float aspect_ratio = o->height / (float)o->width;
         const float d = sc->d.cam.near_clip;
@@ -286,6 +296,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     // band height: a level-0 budget of samples; scenes that can spawn get a smaller one because levels multiply
     int64_t budget = sc->any_spawning_material ? (int64_t)1 << 21 : (int64_t)1 << 24;
     int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
+    if (band_rows < rh) band_rows = std::max(4, band_rows & ~3);       // whole 4-row tiles per band
 
     const bool out_dev = is_device_ptr(rgb_out);
     float* d_out = rgb_out;
@@ -308,10 +319,11 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     for (int by = 0; by < rh; by += band_rows) {
         const int rows = std::min(band_rows, rh - by);
         const int64_t n_pix = (int64_t)rows * rw;
-        int64_t n = n_pix * spp2;
+        const int64_t n_real = n_pix * spp2;
+        int64_t n = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;   // level-0 slots incl. tile padding
         int rc = ensure_level(sc->lv[0], n, nl);
         if (rc != RT_OK) return rc;
-        rt::launch_generate(sc->d, P, sc->lv[0].L, y0 + by, n, s);
+        rt::launch_generate(sc->d, P, sc->lv[0].L, y0 + by, rows, n, s);
         int lvl = 0;
         for (;;) {
             rt::Level& L = sc->lv[lvl].L;
@@ -321,6 +333,12 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
             rt::launch_shadow(exact, sc->d, P, L, n * nl, d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[2], s));
+            if (!sc->any_spawning_material && !timing) {
+                // no material of the scene can spawn rays and nobody asked for counts: the level count is known
+                // (one) and the call stays asynchronous
+                ++lvl;
+                break;
+            }
             HIP_TRY(hipMemcpyAsync(sc->h_counters, sc->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipGetLastError());
@@ -330,7 +348,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
                 HIP_TRY(hipEventElapsedTime(&b, sc->ev[1], sc->ev[2]));
                 ms_extend += a; ms_shadow += b;
             }
-            rays_closest += (uint64_t)n;
+            rays_closest += (uint64_t)(lvl == 0 ? n_real : n);
             unsigned long long traced; memcpy(&traced, sc->h_counters + 2, 8);
             rays_any += traced;
             for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); work[q] += v; }

@@ -63,7 +63,14 @@ struct RenderParams {
     float eps, ray_eps;
     int32_t jitter; uint32_t seed;
     float fl, fr, fb, ft, fd;  // frustum l, r, b, t and near distance d (src/render_thread.cpp:34-40)
+    int32_t row_stride, row_band, row_phase;   // interleaved row shares (row_stride <= 1: rows are image rows)
 };
+
+// image row of local row l (see rt_options.row_stride)
+RT_HD int image_row(const RenderParams& P, int l) {
+    if (P.row_stride <= 1) return l;
+    return ((l / P.row_band) * P.row_stride + P.row_phase) * P.row_band + l % P.row_band;
+}
 
 struct V3 { float x, y, z; };
 

@@ -17,7 +17,8 @@
 
 namespace rt {
 
-enum { RAY_SHADOW = 0, RAY_REFLECT = 1, RAY_REFRACTIVE = 2 };   // src/ray.h:10-14
+enum { RAY_SHADOW = 0, RAY_REFLECT = 1, RAY_REFRACTIVE = 2,      // src/ray.h:10-14
+       RAY_NONE = 3 };                                          // padding slot of a partly covered pixel tile
 enum { RT_MAX_LEVELS = 20 };
 
 struct Level {
@@ -43,16 +44,35 @@ RT_HD float4 mk4(V3 a, float w) { float4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w
 RT_HD V3 point_at(V3 e, V3 d, float t) { return vadd(e, vscale(d, t)); }    // src/ray.cpp:32-35
 
 // ---------------------------------------------------------------------------------------------- generate
-// g = (row_in_band * rw + column_in_rect) * spp^2 + sample; band_y0 = first image row of the band
-RT_HD void body_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int64_t g) {
+// Level-0 nodes are stored tile by tile: 4x4 pixels x spp^2 samples are consecutive, so that the 64 lanes of a wave
+// work on a compact patch of the image (rays that stay together longer) instead of a one-pixel-high strip.
+// Slot of pixel (px, py) of the band (px = column in the rect, py = row in the band), times spp^2, + sample.
+RT_HD int64_t pixel_slot(const RenderParams& P, int px, int py) {
+    const int tiles_x = (P.rw + 3) >> 2;
+    return ((int64_t)((py >> 2) * tiles_x + (px >> 2)) << 4) + ((py & 3) << 2) + (px & 3);
+}
+
+// g = slot * spp^2 + sample; band_y0 = first image row of the band, band_rows = its height
+RT_HD void body_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int band_rows, int64_t g) {
     const int spp2 = P.spp * P.spp;
-    const int pl = (int)(g / spp2), s = (int)(g - (int64_t)pl * spp2);
-    const int i = P.x0 + pl % P.rw, j = band_y0 + pl / P.rw;
+    const int64_t slot = g / spp2;
+    const int s = (int)(g - slot * spp2);
+    const int tiles_x = (P.rw + 3) >> 2;
+    const int64_t tile = slot >> 4;
+    const int q = (int)(slot & 15);
+    const int px = (int)(tile % tiles_x) * 4 + (q & 3), py = (int)(tile / tiles_x) * 4 + (q >> 2);
+    int4 m; m.x = -1; m.z = RT_F2I(1.f); m.w = (int)g;
+    if (px >= P.rw || py >= band_rows) {                           // padding: never traced, never read by the replay
+        m.y = meta_pack(RAY_NONE, 0, 0);
+        L.meta[g] = m;
+        return;
+    }
+    const int i = P.x0 + px, j = image_row(P, band_y0 + py);
     const uint32_t key = node_root(P.seed, (uint32_t)(j * P.W + i), (uint32_t)s);
     const V3 d = primary_dir(sc, P, i, j, s, key);
     L.org[g] = mk4(v3p(sc.cam.pos), RT_I2F((int)key));
     L.dir[g] = mk4(d, 1.f);
-    int4 m; m.x = -1; m.y = meta_pack(RAY_REFLECT, P.D, 0); m.z = RT_F2I(1.f); m.w = (int)g;
+    m.y = meta_pack(RAY_REFLECT, P.D, 0);
     L.meta[g] = m;
 }
 
@@ -80,11 +100,16 @@ RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
 template <bool EXACT>
 RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t i,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    const V3 o = f4v(L.org[i]), d = f4v(L.dir[i]);
-    HitRec h;
-    const bool hit = traverse<false, EXACT>(sc, st, o, d, P.eps, INFINITY, h, n_nodes, n_tris);
+    const int4 m = L.meta[i];
     int2 kd; kd.x = -1; kd.y = 0;
     L.kids[i] = kd;
+    HitRec h;
+    bool hit = false;
+    V3 d = v3(0, 0, 0);
+    if (meta_type(m.y) != RAY_NONE) {
+        d = f4v(L.dir[i]);
+        hit = traverse<false, EXACT>(sc, st, f4v(L.org[i]), d, P.eps, INFINITY, h, n_nodes, n_tris);
+    }
     if (!hit) {
         L.hit[i] = mk4(v3(0, 0, 0), INFINITY);
         L.tri[i] = -1;
@@ -94,7 +119,6 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     L.hit[i] = mk4(n, h.t);
     L.tri[i] = h.tri;
     const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
-    const int4 m = L.meta[i];
     const int depth = meta_depth(m.y);
     if (depth > 0 && M.kind == 2) return P.spr + 1;
     if (depth > 0 && M.kind == 3) {
@@ -234,6 +258,7 @@ struct RFrame {
 // One pixel: pl = row_in_band * rw + column_in_rect.  Writes rgb_out[pl] = sum(colours) / sum(weights).
 RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out) {
     const int spp2 = P.spp * P.spp;
+    const int64_t slot = pixel_slot(P, (int)(pl % P.rw), (int)(pl / P.rw));
     const float Dr = (float)P.Dr;
     float shadow_rec[8];
     for (int q = 0; q < 8; ++q) shadow_rec[q] = 1.f;
@@ -242,7 +267,7 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
     // push order of src/render_thread.cpp:57-109 is sample 0 first, so the last sample pops first
     for (int s = spp2 - 1; s >= 0; --s) {
         int lvl = 0;
-        int64_t i = pl * spp2 + s;
+        int64_t i = slot * spp2 + s;
         V3 cc = v3(0, 0, 0);
         float contrib = 1.f, tpc = 0.f;
         for (;;) {

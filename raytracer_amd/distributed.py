@@ -1,46 +1,91 @@
 """Row-band sharding of a frame over the GPUs of one node.
 
 The reference renders disjoint pixel rectangles on threads that share one framebuffer (reference
-src/main.cpp:474-507); here each rank renders interleaved bands of rows with the scene replicated on its GPU,
-nothing is exchanged while tracing, and the finished rows are gathered once (RCCL all_gather over xGMI when the
-tensors are on GPUs, gloo on CPU for tests)."""
+src/main.cpp:474-507).  Here rank r of N renders every N-th band of `band` rows (band k belongs to rank k % N, so sky
+and geometry rows are spread evenly) in ONE call, with the scene replicated on its GPU; nothing is exchanged while
+tracing, and the finished rows are all-gathered once per frame (RCCL over xGMI for GPU tensors, gloo on CPU in tests).
+"""
 import torch
 import torch.distributed as dist
 
 
 def band_schedule(height, world_size, band_rows=8):
-    """Bands [(y0, y1), ...] of at most band_rows rows, band k owned by rank k % world_size (interleaved so that sky
-    and geometry rows are spread evenly)."""
+    """Bands [(y0, y1), ...] per rank: band k = rows [k*band_rows, (k+1)*band_rows) goes to rank k % world_size."""
     bands = [(y, min(y + band_rows, height)) for y in range(0, height, band_rows)]
     return [[b for k, b in enumerate(bands) if k % world_size == r] for r in range(world_size)]
 
 
-def render_local_bands(render_rect, bands, width, device):
-    """Calls render_rect(x0, y0, x1, y1, out) for each band; returns this rank's rows stacked [n_rows, width, 3]."""
-    n_rows = sum(y1 - y0 for y0, y1 in bands)
-    local = torch.empty((max(n_rows, 1), width, 3), dtype=torch.float32, device=device)
-    r = 0
-    for y0, y1 in bands:
-        render_rect(0, y0, width, y1, local[r:r + (y1 - y0)])
-        r += y1 - y0
-    return local[:n_rows]
+def local_to_image_rows(height, world_size, rank, band_rows=8):
+    """Image row of each local row of `rank`'s share, in local order (the mapping rt_options.row_stride documents)."""
+    rows = []
+    for y0, y1 in band_schedule(height, world_size, band_rows)[rank]:
+        rows.extend(range(y0, y1))
+    return rows
+
+
+class FrameGather:
+    """All-gather of the ranks' row shares into whole frames, reusable across frames (buffers and index are cached)."""
+
+    def __init__(self, height, width, world_size, band_rows, device, group=None):
+        self.h, self.w, self.world, self.group = height, width, world_size, group
+        shares = [local_to_image_rows(height, world_size, r, band_rows) for r in range(world_size)]
+        self.max_rows = max(len(s) for s in shares)
+        self.n_rows = [len(s) for s in shares]
+        # frame row y is row src[y] of the gathered [world * max_rows] stack
+        src = torch.empty(height, dtype=torch.long)
+        for r, s in enumerate(shares):
+            for l, y in enumerate(s):
+                src[y] = r * self.max_rows + l
+        self.src = src.to(device)
+        self.device = device
+
+    def new_local(self):
+        """A buffer for this rank's rows, padded to the largest share so that all ranks gather equal sizes."""
+        return torch.zeros((self.max_rows, self.w, 3), dtype=torch.float32, device=self.device)
+
+    def new_stack(self):
+        return torch.empty((self.world * self.max_rows, self.w, 3), dtype=torch.float32, device=self.device)
+
+    def start(self, local, stack):
+        """Starts the all-gather of `local` into `stack`; returns a handle to pass to finish() (None on one rank)."""
+        if self.world == 1:
+            stack.copy_(local)
+            return None
+        return dist.all_gather_into_tensor(stack.view(-1), local.view(-1), group=self.group, async_op=True)
+
+    def finish(self, work, stack):
+        """Waits for the gather and returns the frame [height, width, 3] in image row order."""
+        if work is not None:
+            work.wait()
+        return stack.index_select(0, self.src)
+
+
+def run_pipelined(steps, render, gather, locals_, stacks):
+    """Renders `steps` frames with render(k, local_buffer) and gathers each one; the gather of frame k runs while frame
+    k+1 renders (two sets of buffers).  Returns the last whole frame (None when steps == 0).
+
+    render(k, buf) must enqueue its work on the current stream; gather is a FrameGather."""
+    pending = [None, None]
+    frame = None
+    for k in range(steps):
+        b = k % 2
+        if pending[b] is not None:                      # buffers of frame k-2 are free once its gather has finished
+            frame = gather.finish(pending[b][0], stacks[b])
+            pending[b] = None
+        render(k, locals_[b])
+        pending[b] = (gather.start(locals_[b], stacks[b]),)
+    for k in (steps, steps + 1):                        # drain in frame order
+        b = k % 2
+        if pending[b] is not None:
+            frame = gather.finish(pending[b][0], stacks[b])
+            pending[b] = None
+    return frame
 
 
 def gather_frame(local_rows, height, width, world_size, band_rows=8, group=None):
-    """All-gathers every rank's rows and puts them back in image order; returns [height, width, 3] on every rank."""
-    sched = band_schedule(height, world_size, band_rows)
-    max_rows = max(sum(y1 - y0 for y0, y1 in b) for b in sched)
-    pad = torch.zeros((max_rows, width, 3), dtype=torch.float32, device=local_rows.device)
-    pad[:local_rows.shape[0]] = local_rows
-    if world_size > 1:
-        parts = [torch.empty_like(pad) for _ in range(world_size)]
-        dist.all_gather(parts, pad, group=group)
-    else:
-        parts = [pad]
-    frame = torch.empty((height, width, 3), dtype=torch.float32, device=local_rows.device)
-    for r in range(world_size):
-        k = 0
-        for y0, y1 in sched[r]:
-            frame[y0:y1] = parts[r][k:k + (y1 - y0)]
-            k += y1 - y0
-    return frame
+    """One-shot form: pads `local_rows` ([n_local, width, 3]), gathers and reorders; returns the whole frame."""
+    fg = FrameGather(height, width, world_size, band_rows, local_rows.device, group)
+    local = fg.new_local()
+    local[:local_rows.shape[0]] = local_rows
+    stack = fg.new_stack()
+    return fg.finish(fg.start(local, stack), stack)

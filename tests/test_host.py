@@ -82,3 +82,8 @@ def test_band_schedule_covers_every_row_once():
         assert rows == list(range(h))
         sizes = [sum(y1 - y0 for y0, y1 in bands) for bands in sched]
         assert max(sizes) - min(sizes) <= b
+        # the closed form the library uses for local row -> image row (rt_options.row_stride)
+        from raytracer_amd.distributed import local_to_image_rows
+        for r in range(n):
+            rows = local_to_image_rows(h, n, r, b)
+            assert rows == [((l // b) * n + r) * b + l % b for l in range(len(rows))]

@@ -147,6 +147,26 @@ def test_rect_and_band_invariance(bunny_scene):
     assert empty.shape == (20, 0, 3)
 
 
+def test_interleaved_row_shares_reassemble_the_frame():
+    """What N ranks would render (each its interleaved bands, one call per rank) is the single-GPU frame."""
+    from raytracer_amd.distributed import local_to_image_rows
+    g = api.TracerScene(scenes.bunny())
+    W, H, band = 96, 54, 4
+    base = dict(width=W, height=H, hfov=60, spp=2, spr=3, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=2)
+    full, _ = g.render_rect(Options(**base), 0, 0, W, H)
+    for world in (2, 3, 8):
+        frame = np.full_like(full, -1.0)
+        for rank in range(world):
+            rows = local_to_image_rows(H, world, rank, band)
+            part, _ = g.render_rect(Options(row_stride=world, row_band=band, row_phase=rank, **base), 0, 0, W, len(rows),
+                                    stats=False)
+            frame[rows] = part
+        assert bits_equal(full, frame).all()
+    with pytest.raises(api.RtError):       # one local row too many
+        n = len(local_to_image_rows(H, 2, 1, band))
+        g.render_rect(Options(row_stride=2, row_band=band, row_phase=1, **base), 0, 0, W, n + 1)
+
+
 def test_bad_arguments_are_reported():
     g = api.TracerScene(scenes.bunny())
     opt = Options(width=64, height=36)

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytracer_amd.distributed import band_schedule, gather_frame, render_local_bands
+from raytracer_amd.distributed import FrameGather, gather_frame, local_to_image_rows, run_pipelined
 
 H, W, BAND = 37, 16, 4
 
@@ -23,11 +23,20 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    bands = band_schedule(H, world, BAND)[rank]
-    local = render_local_bands(_pattern, bands, W, "cpu")
+    rows = local_to_image_rows(H, world, rank, BAND)
+    local = torch.empty((len(rows), W, 3))
+    for l, y in enumerate(rows):                 # stand-in for the renderer: fills local row l with image row y
+        _pattern(0, y, W, y + 1, local[l:l + 1])
     frame = gather_frame(local, H, W, world, BAND)
+    # the benchmark's loop: five frames, gather of frame k overlapped with "rendering" frame k+1; frame k adds k
+    fg = FrameGather(H, W, world, BAND, "cpu")
+    bufs, stacks = [fg.new_local() for _ in range(2)], [fg.new_stack() for _ in range(2)]
+
+    def render(k, buf):
+        buf[:len(rows)] = local + float(k)
+    last = run_pipelined(5, render, fg, bufs, stacks)
     dist.barrier()
-    q.put((rank, frame.numpy()))
+    q.put((rank, frame.numpy(), last.numpy()))
     dist.destroy_process_group()
 
 
@@ -41,7 +50,11 @@ def test_two_ranks_reassemble_the_frame():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in procs)
+    got = {}
+    for _ in procs:
+        r, a, b = q.get(timeout=120)
+        got[r] = a
+        got[(r, "last")] = b
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -49,3 +62,4 @@ def test_two_ranks_reassemble_the_frame():
     _pattern(0, 0, W, H, want)
     for r in (0, 1):
         assert (got[r] == want.numpy()).all()
+        assert (got[(r, "last")] == want.numpy() + 4.0).all()
