@@ -17,27 +17,32 @@
 #define RT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define RT_ATOMIC_INC(p) atomicAdd((p), 1u)
 #define RT_RCP(x) __builtin_amdgcn_rcpf(x)
+#define RT_LDS_PTR __attribute__((address_space(3)))
+#define RT_BLOCK 256      // threads per workgroup of every kernel that traverses (stride of the LDS stack columns)
 // keeps all four lanes of a loaded float4 "used" so that the load stays one 16-byte instruction
 #define RT_KEEP4(q) asm volatile("" ::"v"((q).x), "v"((q).y), "v"((q).z), "v"((q).w))
 
-// Fetch of one 64-byte node.  When every active lane of the wave is at the same node (rays that are still together
-// near the top of the tree) the node is read ONCE through the scalar cache into SGPRs instead of by four 16-byte
-// vector loads per lane: the vector memory pipeline is the busiest unit of the traversal kernels and a wave-wide
-// vector load costs it the same whether the lanes ask for one node or for 64.
+// Fetch of one 64-byte node + the node step.  When every active lane of the wave is at the same node (rays that are
+// still together near the top of the tree) the node is read ONCE through the scalar cache into SGPRs instead of by
+// four 16-byte vector loads per lane: the vector memory pipeline is the busiest unit of the traversal kernels and a
+// wave-wide vector load costs it the same whether the lanes ask for one node or for 64.
 typedef float rt_f16 __attribute__((ext_vector_type(16)));
-#define RT_LOAD_NODE(nodes, cur, q0, q1, q2, q3)                                                            \
+#define RT_NODE_STEP(EXACT, nodes, cur, st, o, d, rd, lim)                                                   \
     do {                                                                                                     \
         const int ucur_ = __builtin_amdgcn_readfirstlane(cur);                                               \
         if (__builtin_amdgcn_ballot_w64((cur) != ucur_) == 0) {                                              \
             rt_f16 s_;                                                                                       \
             const void* up_ = (const void*)((nodes) + ucur_);                                                \
             asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) : "s"(up_) : "memory"); \
-            q0 = make_float4(s_[0], s_[1], s_[2], s_[3]); q1 = make_float4(s_[4], s_[5], s_[6], s_[7]);      \
-            q2 = make_float4(s_[8], s_[9], s_[10], s_[11]); q3 = make_float4(s_[12], s_[13], s_[14], s_[15]); \
+            cur = node_step<EXACT>(s_[0], s_[1], s_[2], s_[3], s_[4], s_[5], s_[6], s_[7], s_[8], s_[9], s_[10],    \
+                                   s_[11], RT_F2I(s_[12]), RT_F2I(s_[13]), RT_F2I(s_[14]), RT_F2I(s_[15]), st, o, d, \
+                                   rd, lim);                                                                 \
         } else {                                                                                             \
             const float4* np_ = reinterpret_cast<const float4*>((nodes) + (cur));                            \
-            q0 = np_[0]; q1 = np_[1]; q2 = np_[2]; q3 = np_[3];                                              \
+            const float4 q0 = np_[0], q1 = np_[1], q2 = np_[2], q3 = np_[3];                                 \
             RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2); RT_KEEP4(q3);                                          \
+            cur = node_step<EXACT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,   \
+                                   RT_F2I(q3.x), RT_F2I(q3.y), RT_F2I(q3.z), RT_F2I(q3.w), st, o, d, rd, lim); \
         }                                                                                                    \
     } while (0)
 #endif
@@ -181,21 +186,21 @@ RT_HD bool slab(const float* b, V3 o, V3 d, V3 rd, float& tmin) {
 #define RT_LDS_SLOTS 16   // stack entries per lane kept in LDS; deeper entries go to a per-lane array
 
 // Per-lane stack of postponed child references.  The first RT_LDS_SLOTS entries live in LDS, laid out
-// [slot][lane of the workgroup] so that a wave's access to one slot is conflict-free; the rest spill to private
-// memory.  Near-first descent rarely holds more than a handful of entries.
+// [slot][lane of the workgroup] so that a wave's access to one slot is conflict-free; the rest spill to a private
+// array.  Near-first descent rarely holds more than a handful of entries.  The struct holds only scalars (the spill
+// array is a separate object) so that it stays in registers.
 struct StackLds {
-    int32_t* lds;            // this lane's column: slot s is lds[s * stride]
-    int stride;
-    int32_t spill[RT_STACK - RT_LDS_SLOTS];
+    RT_LDS_PTR int32_t* lds; // this lane's column: slot s is lds[s * RT_BLOCK]
+    int32_t* spill;          // RT_STACK - RT_LDS_SLOTS entries
     int sp;
     RT_HDM void push(int32_t v) {
-        if (sp < RT_LDS_SLOTS) lds[sp * stride] = v;
+        if (sp < RT_LDS_SLOTS) lds[sp * RT_BLOCK] = v;
         else if (sp < RT_STACK) spill[sp - RT_LDS_SLOTS] = v;
         ++sp;
     }
     RT_HDM int32_t pop() {
         --sp;
-        return (sp < RT_LDS_SLOTS) ? lds[sp * stride] : spill[sp - RT_LDS_SLOTS];
+        return (sp < RT_LDS_SLOTS) ? lds[sp * RT_BLOCK] : spill[sp - RT_LDS_SLOTS];
     }
 };
 
@@ -237,6 +242,31 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
     return true;
 }
 
+// One inner node: tests both children and returns the next reference to visit (the far child is pushed when both are
+// hit; RT_NONE when the stack is empty).  The sixteen node words are passed as scalars so that the same code serves
+// words held in vector registers and words held in scalar registers (a node the whole wave fetched once).
+template <bool EXACT>
+RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8,
+                        float b9, float b10, float b11, int32_t r0, int32_t r1, int32_t r2, int32_t r3, StackLds& st,
+                        V3 o, V3 d, V3 rd, float lim) {
+    const float lb[6] = {b0, b1, b2, b3, b4, b5};
+    const float rb[6] = {b6, b7, b8, b9, b10, b11};
+    // the reference's own leaves when its exact box tests are asked for, the refined ones otherwise
+    const int32_t lref = EXACT ? r0 : r2, rref = EXACT ? r1 : r3;
+    float tl, tr;
+    bool hl = slab<EXACT>(lb, o, d, rd, tl);
+    bool hr = slab<EXACT>(rb, o, d, rd, tr) && (rref != RT_NONE);
+    if (!EXACT) { hl = hl && !(tl > lim); hr = hr && !(tr > lim); }
+    if (hl && hr) {
+        const bool swap = !EXACT && tr < tl;
+        st.push(swap ? lref : rref);
+        return swap ? rref : lref;
+    }
+    if (hl) return lref;
+    if (hr) return rref;
+    return st.sp ? st.pop() : RT_NONE;
+}
+
 // Nearest hit (ANY == false) or any hit (ANY == true) with t in [t0, t1].
 // Returns true on a hit.  Nearest: best = the candidate minimal in (t, tie rank) order, which is the reference's
 // choice among equal t (ranks: see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
@@ -256,27 +286,9 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
     for (;;) {
         // ---- descend until a leaf is reached (cur < 0) or nothing is left (cur == RT_NONE)
         while (cur >= 0) {
-            float4 q0, q1, q2, q3;
-            RT_LOAD_NODE(sc.nodes, cur, q0, q1, q2, q3);
             if (n_nodes) ++*n_nodes;
-            const float lb[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-            const float rb[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-            // the reference's own leaves when its exact box tests are asked for, the refined ones otherwise
-            const int32_t lref = RT_F2I(EXACT ? q3.x : q3.z), rref = RT_F2I(EXACT ? q3.y : q3.w);
-            float tl, tr;
-            bool hl = slab<EXACT>(lb, o, d, rd, tl);
-            bool hr = slab<EXACT>(rb, o, d, rd, tr) && (rref != RT_NONE);
-            if (!EXACT) {
-                const float lim = ANY ? t1 : best.t;
-                hl = hl && !(tl > lim); hr = hr && !(tr > lim);
-            }
-            if (hl && hr) {
-                const bool swap = !EXACT && tr < tl;
-                st.push(swap ? lref : rref);
-                cur = swap ? rref : lref;
-            } else if (hl) cur = lref;
-            else if (hr) cur = rref;
-            else cur = st.sp ? st.pop() : RT_NONE;
+            const float lim = EXACT ? INFINITY : (ANY ? t1 : best.t);
+            RT_NODE_STEP(EXACT, sc.nodes, cur, st, o, d, rd, lim);
         }
         if (cur == RT_NONE) break;
         // ---- one leaf: a run of consecutive triangles
