@@ -83,14 +83,18 @@ void free_level(LevelBuf& b) {
     b = LevelBuf();
 }
 
-int ensure_level(LevelBuf& b, int64_t n, int lights) {
+// implicit: level 0, whose rays are recomputed instead of stored (no org/dir/meta arrays)
+int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit) {
     lights = std::max(lights, 1);
     if (b.cap >= n && b.lights >= lights) return RT_OK;
     const int64_t cap = std::max<int64_t>(n + n / 4, 1024);
     free_level(b);
-    HIP_TRY(hipMalloc((void**)&b.L.org, cap * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&b.L.dir, cap * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&b.L.meta, cap * sizeof(int4)));
+    b.L.implicit = implicit ? 1 : 0;
+    if (!implicit) {
+        HIP_TRY(hipMalloc((void**)&b.L.org, cap * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&b.L.dir, cap * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&b.L.meta, cap * sizeof(int4)));
+    }
     HIP_TRY(hipMalloc((void**)&b.L.hit, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&b.L.tri, cap * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&b.L.kids, cap * sizeof(int2)));
@@ -281,6 +285,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     P.spp = o->spp; P.spr = o->spr; P.D = o->max_bounce; P.Dr = o->max_refrac_bounce;
     P.eps = o->eps; P.ray_eps = o->ray_eps; P.jitter = o->jitter_mode; P.seed = o->seed;
     P.row_stride = o->row_stride; P.row_band = o->row_band; P.row_phase = o->row_phase;
+    P.can_spawn = sc->any_spawning_material ? 1 : 0;
     {   // src/render_thread.cpp:34-40 (PI is the float 3.1415926, :3)
         const float aspect_ratio = o->height / (float)o->width;
         const float d = sc->d.cam.near_clip;
@@ -321,9 +326,9 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         const int64_t n_pix = (int64_t)rows * rw;
         const int64_t n_real = n_pix * spp2;
         int64_t n = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;   // level-0 slots incl. tile padding
-        int rc = ensure_level(sc->lv[0], n, nl);
+        int rc = ensure_level(sc->lv[0], n, nl, true);
         if (rc != RT_OK) return rc;
-        rt::launch_generate(sc->d, P, sc->lv[0].L, y0 + by, rows, n, s);
+        P.band_y0 = y0 + by; P.band_rows = rows;
         int lvl = 0;
         for (;;) {
             rt::Level& L = sc->lv[lvl].L;
@@ -356,7 +361,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
             ++lvl;
             if (kids == 0) break;
             if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");
-            rc = ensure_level(sc->lv[lvl], kids, nl);
+            rc = ensure_level(sc->lv[lvl], kids, nl, false);
             if (rc != RT_OK) return rc;
             rt::launch_spawn(sc->d, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);
             n = kids;

@@ -69,6 +69,8 @@ struct RenderParams {
     int32_t jitter; uint32_t seed;
     float fl, fr, fb, ft, fd;  // frustum l, r, b, t and near distance d (src/render_thread.cpp:34-40)
     int32_t row_stride, row_band, row_phase;   // interleaved row shares (row_stride <= 1: rows are image rows)
+    int32_t band_y0, band_rows;                // the band of rows being rendered: first (local) row and height
+    int32_t can_spawn;                         // some material of the scene spawns rays (Phong / refractive)
 };
 
 // image row of local row l (see rt_options.row_stride)

@@ -2,7 +2,8 @@
 // rt_kernels.hip only compute the lane's index and reduce counters.
 //
 // Pipeline for one band of pixels (all stages cite the reference's src/render_thread.cpp):
-//   generate : level-0 nodes = primary render rays (:57-94)
+//   generate : level-0 nodes = primary render rays (:57-94); implicit - every kernel recomputes the primary ray of its
+//              node from the node's number instead of reading a stored copy
 //   per level, while the level is not empty:
 //     extend : nearest hit of every node's ray (:122 for render rays; the shadow-type twin that the reference
 //              traces along the same ray, :97-104 / :269-280, has the same answer and is not traced again)
@@ -32,6 +33,16 @@ struct Level {
     float* aux;        // Schlick term r_theta of a refractive spawn
     uint32_t* unocc;   // [n][n_lights] light rays that reached the light, out of spr+1 (written only where the
                        // node's companion shadow ray hit)
+    int32_t implicit;  // 1: level 0 - org/dir/meta are not stored; node g IS the primary ray of slot g / spp^2,
+                       // sample g % spp^2, and is recomputed wherever it is needed (cheaper than 48 B per sample)
+};
+
+// What the kernels need to know about a node's ray.
+struct NodeIn {
+    V3 o, d; uint32_t key; float weight;
+    int32_t packed;      // type | depth << 8 | rank << 16
+    int32_t refraci;     // float bits
+    int32_t comp;        // node whose ray the companion shadow ray repeats
 };
 
 RT_HD int meta_type(int y) { return y & 0xff; }
@@ -52,8 +63,8 @@ RT_HD int64_t pixel_slot(const RenderParams& P, int px, int py) {
     return ((int64_t)((py >> 2) * tiles_x + (px >> 2)) << 4) + ((py & 3) << 2) + (px & 3);
 }
 
-// g = slot * spp^2 + sample; band_y0 = first image row of the band, band_rows = its height
-RT_HD void body_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int band_rows, int64_t g) {
+// Node g of the implicit level 0: g = slot * spp^2 + sample (src/render_thread.cpp:57-94).
+RT_HD NodeIn primary_node(const DScene& sc, const RenderParams& P, int64_t g) {
     const int spp2 = P.spp * P.spp;
     const int64_t slot = g / spp2;
     const int s = (int)(g - slot * spp2);
@@ -61,19 +72,28 @@ RT_HD void body_generate(const DScene& sc, const RenderParams& P, const Level& L
     const int64_t tile = slot >> 4;
     const int q = (int)(slot & 15);
     const int px = (int)(tile % tiles_x) * 4 + (q & 3), py = (int)(tile / tiles_x) * 4 + (q >> 2);
-    int4 m; m.x = -1; m.z = RT_F2I(1.f); m.w = (int)g;
-    if (px >= P.rw || py >= band_rows) {                           // padding: never traced, never read by the replay
-        m.y = meta_pack(RAY_NONE, 0, 0);
-        L.meta[g] = m;
-        return;
+    NodeIn n;
+    n.o = v3p(sc.cam.pos); n.d = v3(0, 0, 0); n.key = 0; n.weight = 1.f;
+    n.refraci = RT_F2I(1.f); n.comp = (int32_t)g;
+    if (px >= P.rw || py >= P.band_rows) {                         // padding of a partly covered tile: never traced
+        n.packed = meta_pack(RAY_NONE, 0, 0);
+        return n;
     }
-    const int i = P.x0 + px, j = image_row(P, band_y0 + py);
-    const uint32_t key = node_root(P.seed, (uint32_t)(j * P.W + i), (uint32_t)s);
-    const V3 d = primary_dir(sc, P, i, j, s, key);
-    L.org[g] = mk4(v3p(sc.cam.pos), RT_I2F((int)key));
-    L.dir[g] = mk4(d, 1.f);
-    m.y = meta_pack(RAY_REFLECT, P.D, 0);
-    L.meta[g] = m;
+    const int i = P.x0 + px, j = image_row(P, P.band_y0 + py);
+    n.key = node_root(P.seed, (uint32_t)(j * P.W + i), (uint32_t)s);
+    n.d = primary_dir(sc, P, i, j, s, n.key);
+    n.packed = meta_pack(RAY_REFLECT, P.D, 0);
+    return n;
+}
+
+RT_HD NodeIn node_in(const DScene& sc, const RenderParams& P, const Level& L, int64_t i) {
+    if (L.implicit) return primary_node(sc, P, i);
+    const float4 o = L.org[i], d = L.dir[i];
+    const int4 m = L.meta[i];
+    NodeIn n;
+    n.o = f4v(o); n.d = f4v(d); n.key = (uint32_t)RT_F2I(o.w); n.weight = d.w;
+    n.packed = m.y; n.refraci = m.z; n.comp = m.w;
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------ extend
@@ -100,16 +120,13 @@ RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
 template <bool EXACT>
 RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t i,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    const int4 m = L.meta[i];
-    int2 kd; kd.x = -1; kd.y = 0;
-    L.kids[i] = kd;
+    const NodeIn in = node_in(sc, P, L, i);
+    if (P.can_spawn) { int2 kd; kd.x = -1; kd.y = 0; L.kids[i] = kd; }
     HitRec h;
     bool hit = false;
-    V3 d = v3(0, 0, 0);
-    if (meta_type(m.y) != RAY_NONE) {
-        d = f4v(L.dir[i]);
-        hit = traverse<false, EXACT>(sc, st, f4v(L.org[i]), d, P.eps, INFINITY, h, n_nodes, n_tris);
-    }
+    const V3 d = in.d;
+    if (meta_type(in.packed) != RAY_NONE)
+        hit = traverse<false, EXACT>(sc, st, in.o, d, P.eps, INFINITY, h, n_nodes, n_tris);
     if (!hit) {
         L.hit[i] = mk4(v3(0, 0, 0), INFINITY);
         L.tri[i] = -1;
@@ -118,12 +135,13 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     const V3 n = hit_normal(sc, h);
     L.hit[i] = mk4(n, h.t);
     L.tri[i] = h.tri;
+    if (!P.can_spawn) return 0;
     const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
-    const int depth = meta_depth(m.y);
+    const int depth = meta_depth(in.packed);
     if (depth > 0 && M.kind == 2) return P.spr + 1;
     if (depth > 0 && M.kind == 3) {
         V3 td;
-        const float r_theta = refract_dir(d, n, RT_I2F(m.z), M.refractivity, td);
+        const float r_theta = refract_dir(d, n, RT_I2F(in.refraci), M.refractivity, td);
         L.aux[i] = r_theta;
         return (r_theta <= 0) ? 1 : 2;                              // src/render_thread.cpp:345
     }
@@ -138,10 +156,11 @@ RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, S
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     const int64_t i = w / sc.n_lights;
     const int li = (int)(w - i * sc.n_lights);
-    const int comp = L.meta[i].w;
+    const int comp = L.implicit ? (int)i : L.meta[i].w;
     if (L.tri[comp] < 0) return 0;                                  // the shadow-type ray missed: record stays stale
-    const V3 p = point_at(f4v(L.org[comp]), f4v(L.dir[comp]), L.hit[comp].w);
-    const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
+    const NodeIn cin = node_in(sc, P, L, comp);
+    const V3 p = point_at(cin.o, cin.d, L.hit[comp].w);
+    const uint32_t key = L.implicit ? cin.key : (uint32_t)RT_F2I(L.org[i].w);
     const V3 exact = vnorm(light_dir(sc.lights[li], p, P, key, SITE_SH_LIGHT, (uint32_t)li));   // Ray ctor normalises
     uint32_t unocc = 0;
     for (int k = 0; k <= P.spr; ++k) {
@@ -157,16 +176,16 @@ RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, S
 RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
     const int tri = L.tri[i];
     if (tri < 0) return;
-    const int4 m = L.meta[i];
-    const int depth = meta_depth(m.y);
+    const NodeIn in = node_in(sc, P, L, i);
+    const int depth = meta_depth(in.packed);
     const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
     if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
-    const V3 o = f4v(L.org[i]), d = f4v(L.dir[i]);
+    const V3 o = in.o, d = in.d;
     const float4 hn = L.hit[i];
     const V3 n = f4v(hn);
     const float t = hn.w;
-    const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
-    const float weight = L.dir[i].w;
+    const uint32_t key = in.key;
+    const float weight = in.weight;
     const V3 p = point_at(o, d, t);
     // mirror direction, src/linmath.h:59-65
     const float pp = 2.f * vdot(d, n);
@@ -179,13 +198,13 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
             const uint32_t ck = node_child(key, (uint32_t)k);
             N.org[base + k] = mk4(p, RT_I2F((int)ck));
             N.dir[base + k] = mk4(dk, weight);
-            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = m.z; cm.w = (int)(base + P.spr);
+            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = in.refraci; cm.w = (int)(base + P.spr);
             N.meta[base + k] = cm;
         }
         int2 kd; kd.x = (int)base; kd.y = cnt;
         L.kids[i] = kd;
     } else {                                                        // src/render_thread.cpp:318-394
-        const float refraci = RT_I2F(m.z);
+        const float refraci = RT_I2F(in.refraci);
         V3 td = v3(0, 0, 0);
         const float r_theta = refract_dir(d, n, refraci, M.refractivity, td);
         const bool both = !(r_theta <= 0);
@@ -273,11 +292,11 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
         for (;;) {
             // ---- pop one render ray: node i of level lvl with colour state (cc, contrib, tpc)
             const Level& L = lv[lvl];
-            const int4 m = L.meta[i];
-            const int type = meta_type(m.y), depth = meta_depth(m.y);
-            const float weight = L.dir[i].w;
+            const NodeIn in = node_in(sc, P, L, i);
+            const int type = meta_type(in.packed), depth = meta_depth(in.packed);
+            const float weight = in.weight;
             // its companion shadow-type ray pops just before it (:134-171)
-            if (L.tri[m.w] >= 0)
+            if (L.tri[in.comp] >= 0)
                 for (int li = 0; li < sc.n_lights; ++li) {
                     float sh_frac = (float)L.unocc[i * sc.n_lights + li];    // +1 per light ray that hit nothing
                     sh_frac /= (float)(P.spr + 1);
@@ -290,8 +309,8 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
                 const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
                 const float4 hn = L.hit[i];
                 const V3 n = f4v(hn);
-                const V3 p = point_at(f4v(L.org[i]), f4v(L.dir[i]), hn.w);
-                const uint32_t key = (uint32_t)RT_F2I(L.org[i].w);
+                const V3 p = point_at(in.o, in.d, hn.w);
+                const uint32_t key = in.key;
                 const bool use_refl = (M.kind == 2 || M.kind == 3), use_refr = (M.kind == 3);
                 if (!use_refl) {                                                 // :187-200
                     V3 add = apply_shade(sc, P, M, p, n, shadow_rec, key);
@@ -315,7 +334,7 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
                     c = cc; draw = true;
                 } else {                                                         // :300-397
                     V3 c_add;
-                    if (RT_I2F(m.z) == M.refractivity) {
+                    if (RT_I2F(in.refraci) == M.refractivity) {
                         c_add.x = M.transp[0] * expf(-M.transp[0] * hn.w);
                         c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
                         c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);

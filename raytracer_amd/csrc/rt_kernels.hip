@@ -18,11 +18,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_generate(DScene sc, RenderParams P, Level L, int band_y0, int band_rows, int64_t n) {
-    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (g < n) body_generate(sc, P, L, band_y0, band_rows, g);
-}
-
 // work[0] += inner nodes fetched, work[1] += triangles tested (COUNT builds only)
 template <bool COUNT>
 __device__ __forceinline__ void add_work(unsigned long long* work, uint32_t nn, uint32_t nt) {
@@ -81,9 +76,6 @@ inline unsigned blocks(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); 
 
 }  // namespace
 
-void launch_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int band_rows, int64_t n, hipStream_t s) {
-    if (n > 0) k_generate<<<blocks(n), BLOCK, 0, s>>>(sc, P, L, band_y0, band_rows, n);
-}
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
                    unsigned long long* work, hipStream_t s) {
     if (n <= 0) return;

@@ -6,8 +6,6 @@ namespace rt {
 
 struct LevelSet { Level lv[RT_MAX_LEVELS]; };
 
-// n = level-0 slots of the band: tiles of 4x4 pixels (partly covered tiles are padded) x spp^2
-void launch_generate(const DScene& sc, const RenderParams& P, const Level& L, int band_y0, int band_rows, int64_t n, hipStream_t s);
 // counters[0] += number of children the level will spawn
 // work (may be NULL): work[0] += inner nodes fetched, work[1] += triangles tested
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
