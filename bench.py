@@ -38,6 +38,9 @@ WORKLOADS = {
                           dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, ray_eps=0.1)),
     "mirror_room": (lambda: scenes.mirror_room(), dict(width=1827, height=1077, hfov=60, spp=2, spr=3, max_bounce=3,
                                                         eps=1e-3, ray_eps=0.01)),
+    # configs[4]: ~10 M triangles (2013 bunnies, mixed materials), 3840x2160 at 64 spp; one step takes seconds
+    "bunny_field_4k": (lambda: scenes.bunny_field(), dict(width=3840, height=2160, hfov=54.5, spp=8, spr=3, max_bounce=3,
+                                                           max_refrac_bounce=3, eps=1e-3, ray_eps=0.1)),
     "glass_balls": (lambda: scenes.glass_balls(), dict(width=1920, height=1080, hfov=54.5, spp=2, spr=4, max_bounce=3,
                                                         max_refrac_bounce=5, eps=1e-3, ray_eps=0.1)),
 }
@@ -164,8 +167,10 @@ def roofline(tracer, opt, W, H, dev, stream):
     ms_ext, ms_sha, ms_shade = float(np.mean(ext)), float(np.mean(sha)), float(np.mean(shade))
     # per ray: the node's queue records it reads/writes + 64 B per inner node fetched + 48 B per triangle tested
     # (+ 36 B of vertex normals for a nearest hit); DESIGN.md "Kernels" states these figures
-    b_ext = cs.rays_closest * (48 + 28 + 36) + 64 * cs.nodes_extend + 48 * cs.tris_extend
-    b_sha = cs.rays_any * (16 + 4 + 16 + 16 + 16 + 4) + 64 * cs.nodes_shadow + 48 * cs.tris_shadow
+    # queue records: a nearest-hit ray writes hit (16 B) + triangle (4 B) and reads 36 B of normals on a hit; one
+    # (node, light) item of spr+1 light rays reads triangle + hit (20 B) and writes its count (4 B)
+    b_ext = cs.rays_closest * (20 + 36) + 64 * cs.nodes_extend + 48 * cs.tris_extend
+    b_sha = cs.rays_any // (opt.spr + 1) * 24 + 64 * cs.nodes_shadow + 48 * cs.tris_shadow
     if ms_sha >= ms_ext:
         name, b, ms, rays, nn, nt = "k_shadow (any-hit light rays)", b_sha, ms_sha, cs.rays_any, cs.nodes_shadow, cs.tris_shadow
     else:

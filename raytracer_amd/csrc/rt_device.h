@@ -179,8 +179,17 @@ RT_HD bool slab(const float* b, V3 o, V3 d, V3 rd, float& tmin) {
     }
     tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
     const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    return !(tmax < 0.f || tmin > tmax);
+    if (EXACT) return !(tmax < 0.f || tmin > tmax);
+    // the reciprocal form is a few units in the last place off; widening the exit distance by that much keeps a
+    // ray that passes exactly through a box corner or edge (a shared vertex of a mesh) from slipping between boxes
+    return !(tmax < 0.f || tmin > tmax * 1.000001f);
 }
+
+// Pruning bound for "this subtree starts beyond the best hit so far".  The triangle distances it is compared with
+// are rounded results of a different formula than the box distances, so equal or almost equal hits in different
+// leaves (a ray through a shared vertex or edge) must all be looked at: the reference picks among them by (t, tie
+// rank), which needs every candidate.
+RT_HD float prune_limit(float best_t) { return best_t * 1.00001f; }
 
 #ifndef RT_STACK
 #define RT_STACK 96       // deepest tree the traversal accepts (checked when the scene is created)
@@ -289,7 +298,7 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
         // ---- descend until a leaf is reached (cur < 0) or nothing is left (cur == RT_NONE)
         while (cur >= 0) {
             if (n_nodes) ++*n_nodes;
-            const float lim = EXACT ? INFINITY : (ANY ? t1 : best.t);
+            const float lim = EXACT ? INFINITY : (ANY ? t1 : prune_limit(best.t));
             RT_NODE_STEP(EXACT, sc.nodes, cur, st, o, d, rd, lim);
         }
         if (cur == RT_NONE) break;

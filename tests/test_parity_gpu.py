@@ -147,6 +147,45 @@ def test_rect_and_band_invariance(bunny_scene):
     assert empty.shape == (20, 0, 3)
 
 
+def test_many_meshes_mixed_materials(oracle_mod):
+    """An instanced field (61 meshes, 200 k triangles, Lambert / Phong / refractive at random): the top tree over
+    mesh boxes answers like the reference's loop over meshes, and a small frame matches within the refractive bar.
+    Half of the rays pass exactly through mesh vertices: there the reference's own box tests decide by the last bit
+    whether a leaf is looked at, so only the reference's slab arithmetic (exact_boxes) can agree on every ray; the
+    pruning traversal widens its box tests instead and must never return a farther hit than the reference."""
+    sc = scenes.bunny_field(40, seed=11)
+    g, o = _pair(sc, oracle_mod)
+    assert g.info()["tris"] == sc.n_tris
+    P = np.concatenate([m.pos.reshape(-1, 3)[::50] for m in sc.meshes])
+    c = P.mean(0)
+    org, d = random_rays(20000, 21, center=c, spread=30.0)
+    rng = np.random.RandomState(4)
+    k = len(org) // 2
+    tgt = P[rng.randint(len(P), size=k)]
+    dd = tgt - org[-k:]
+    d[-k:] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
+    to, trio, nro = o.trace(org, d, 1e-3, np.inf)
+    for exact in (True, False):
+        tg, trig, nrg = g.trace(org, d, 1e-3, np.inf, exact_boxes=exact)
+        same = trio == trig
+        assert bits_equal(to[same], tg[same]).all() and bits_equal(nro[same], nrg[same]).all()
+        if exact:
+            assert same.all()
+            continue
+        assert same[:-k].mean() >= 0.9999 and same[-k:].mean() >= 0.99
+        t_ref = np.where(trio >= 0, to, np.inf)
+        t_gpu = np.where(trig >= 0, tg, np.inf)
+        assert (t_gpu <= t_ref * (1 + 1e-5)).all()
+    assert (trio >= 0).mean() > 0.3
+    opt = Options(width=64, height=36, hfov=54.5, spp=2, spr=2, max_bounce=2, max_refrac_bounce=3, eps=1e-3,
+                  jitter_mode=RT_JITTER_HASH, seed=3, exact_boxes=1)
+    a, _ = o.render_rect(opt, 8, 4, 56, 30)
+    b, _ = g.render_rect(opt, 8, 4, 56, 30)
+    assert (np.isnan(a) == np.isnan(b)).all()
+    fin = np.isfinite(a)
+    assert np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6)
+
+
 def test_interleaved_row_shares_reassemble_the_frame():
     """What N ranks would render (each its interleaved bands, one call per rank) is the single-GPU frame."""
     from raytracer_amd.distributed import local_to_image_rows
