@@ -41,6 +41,8 @@ struct LevelBuf {
 
 }  // namespace
 
+enum { RT_N_COUNTERS = 16 + rt::RT_TRACED_SLOTS * rt::RT_TRACED_STRIDE * 2 };   // u32 words of the counter block
+
 struct rt_scene {
     int device = 0;
     rt::DScene d{};
@@ -51,7 +53,7 @@ struct rt_scene {
     // render workspace, grown on demand; one render at a time per scene
     std::mutex mu;
     LevelBuf lv[rt::RT_MAX_LEVELS];
-    uint32_t* d_counters = nullptr;          // [0] children of the level, [1] spawn cursor, [2..3] light rays (u64),
+    uint32_t* d_counters = nullptr;          // [0] children of the level, [1] spawn cursor, [16...] light-ray slots (u64),
                                              // [4..7] extend nodes/tris (2 x u64), [8..11] shadow nodes/tris
     uint32_t* h_counters = nullptr;          // pinned mirror
     float* d_stage = nullptr; int64_t stage_cap = 0;
@@ -183,8 +185,8 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     sc->n_inner = (int64_t)flat.nodes.size();
     sc->n_leaves = flat.n_leaves;
     sc->max_depth = flat.max_depth;
-    hipError_t e = hipMalloc((void**)&sc->d_counters, 16 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, 16 * sizeof(uint32_t));
+    hipError_t e = hipMalloc((void**)&sc->d_counters, RT_N_COUNTERS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, RT_N_COUNTERS * sizeof(uint32_t));
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&sc->ev[i]);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, hipGetErrorString(e)); }
     *out = sc;
@@ -319,7 +321,8 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     }
     uint64_t rays_closest = 0, rays_any = 0;
     int max_levels = 0;
-    unsigned long long* d_traced = (unsigned long long*)(sc->d_counters + 2);
+    // light rays traced: only counted when the caller asked for statistics (the count costs an atomic per wave)
+    unsigned long long* d_traced = timing ? (unsigned long long*)(sc->d_counters + 16) : nullptr;
 
     for (int by = 0; by < rh; by += band_rows) {
         const int rows = std::min(band_rows, rh - by);
@@ -332,7 +335,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         int lvl = 0;
         for (;;) {
             rt::Level& L = sc->lv[lvl].L;
-            HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(sc->d_counters, 0, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), s));
             if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
             rt::launch_extend(exact, sc->d, P, L, n, sc->d_counters, counting ? (unsigned long long*)(sc->d_counters + 4) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
@@ -344,7 +347,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
                 ++lvl;
                 break;
             }
-            HIP_TRY(hipMemcpyAsync(sc->h_counters, sc->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(sc->h_counters, sc->d_counters, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipGetLastError());
             if (timing) {
@@ -354,8 +357,11 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
                 ms_extend += a; ms_shadow += b;
             }
             rays_closest += (uint64_t)(lvl == 0 ? n_real : n);
-            unsigned long long traced; memcpy(&traced, sc->h_counters + 2, 8);
-            rays_any += traced;
+            if (timing)
+                for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) {
+                    unsigned long long v; memcpy(&v, sc->h_counters + 16 + q * rt::RT_TRACED_STRIDE * 2, 8);
+                    rays_any += v;
+                }
             for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); work[q] += v; }
             const int64_t kids = sc->h_counters[0];
             ++lvl;

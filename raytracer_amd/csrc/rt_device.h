@@ -27,22 +27,22 @@
 // four 16-byte vector loads per lane: the vector memory pipeline is the busiest unit of the traversal kernels and a
 // wave-wide vector load costs it the same whether the lanes ask for one node or for 64.
 typedef float rt_f16 __attribute__((ext_vector_type(16)));
-#define RT_NODE_STEP(EXACT, nodes, cur, st, o, d, rd, lim)                                                   \
+#define RT_NODE_STEP(EXACT, OCT, nodes, cur, st, o, d, rd, lo, lim)                                          \
     do {                                                                                                     \
         const int ucur_ = __builtin_amdgcn_readfirstlane(cur);                                               \
         if (__builtin_amdgcn_ballot_w64((cur) != ucur_) == 0) {                                              \
             rt_f16 s_;                                                                                       \
             const void* up_ = (const void*)((nodes) + ucur_);                                                \
             asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) : "s"(up_) : "memory"); \
-            cur = node_step<EXACT>(s_[0], s_[1], s_[2], s_[3], s_[4], s_[5], s_[6], s_[7], s_[8], s_[9], s_[10],    \
+            cur = node_step<EXACT, OCT>(s_[0], s_[1], s_[2], s_[3], s_[4], s_[5], s_[6], s_[7], s_[8], s_[9], s_[10], \
                                    s_[11], RT_F2I(s_[12]), RT_F2I(s_[13]), RT_F2I(s_[14]), RT_F2I(s_[15]), st, o, d, \
-                                   rd, lim);                                                                 \
+                                   rd, lo, lim);                                                             \
         } else {                                                                                             \
             const float4* np_ = reinterpret_cast<const float4*>((nodes) + (cur));                            \
             const float4 q0 = np_[0], q1 = np_[1], q2 = np_[2], q3 = np_[3];                                 \
             RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2); RT_KEEP4(q3);                                          \
-            cur = node_step<EXACT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w,   \
-                                   RT_F2I(q3.x), RT_F2I(q3.y), RT_F2I(q3.z), RT_F2I(q3.w), st, o, d, rd, lim); \
+            cur = node_step<EXACT, OCT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, \
+                                   RT_F2I(q3.x), RT_F2I(q3.y), RT_F2I(q3.z), RT_F2I(q3.w), st, o, d, rd, lo, lim); \
         }                                                                                                    \
     } while (0)
 #endif
@@ -160,36 +160,63 @@ RT_HD V3 split_dir(V3 exact, float eps, const RenderParams& P, uint32_t node, ui
 // ---- traversal ---------------------------------------------------------------------------------------------
 struct HitRec { float t; int32_t tri; int32_t rank; float beta, gamma; };   // tri = position in the triangle array, -1 = none
 
-// Slab test of one box.  EXACT: the reference's arithmetic (src/geometry.cpp:25-37: six true divisions, fmin/fmax
-// that drop NaNs).  Otherwise a multiplication by the precomputed reciprocal replaces each division; tmin is
-// returned for nearest-first ordering and pruning.
-template <bool EXACT>
-RT_HD bool slab(const float* b, V3 o, V3 d, V3 rd, float& tmin) {
-    float t1, t2, t3, t4, t5, t6;
-    if (EXACT) {
-        t1 = (b[0] - o.x) / d.x; t2 = (b[3] - o.x) / d.x;
-        t3 = (b[1] - o.y) / d.y; t4 = (b[4] - o.y) / d.y;
-        t5 = (b[2] - o.z) / d.z; t6 = (b[5] - o.z) / d.z;
-    } else {
-        // (bound - e) * (1/d): the subtraction is the reference's, so d == 0 gives the same +-inf / NaN pattern
-        // as its division (a fused b*rd - e*rd would turn inf - inf into NaN and lose the slab)
-        t1 = (b[0] - o.x) * rd.x; t2 = (b[3] - o.x) * rd.x;
-        t3 = (b[1] - o.y) * rd.y; t4 = (b[4] - o.y) * rd.y;
-        t5 = (b[2] - o.z) * rd.z; t6 = (b[5] - o.z) * rd.z;
-    }
+// Slab test of one box with the reference's arithmetic (src/geometry.cpp:25-37: six true divisions, fmin/fmax that
+// drop NaNs).
+RT_HD bool slab_exact(const float* b, V3 o, V3 d, float& tmin) {
+    const float t1 = (b[0] - o.x) / d.x, t2 = (b[3] - o.x) / d.x;
+    const float t3 = (b[1] - o.y) / d.y, t4 = (b[4] - o.y) / d.y;
+    const float t5 = (b[2] - o.z) / d.z, t6 = (b[5] - o.z) / d.z;
     tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
     const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    if (EXACT) return !(tmax < 0.f || tmin > tmax);
-    // the reciprocal form is a few units in the last place off; widening the exit distance by that much keeps a
-    // ray that passes exactly through a box corner or edge (a shared vertex of a mesh) from slipping between boxes
-    return !(tmax < 0.f || tmin > tmax * 1.000001f);
+    return !(tmax < 0.f || tmin > tmax);
 }
 
-// Pruning bound for "this subtree starts beyond the best hit so far".  The triangle distances it is compared with
-// are rounded results of a different formula than the box distances, so equal or almost equal hits in different
-// leaves (a ray through a shared vertex or edge) must all be looked at: the reference picks among them by (t, tie
-// rank), which needs every candidate.
+// Slab test of the pruning traversal: is some t of [lo, lim] inside the box?  A multiplication by the precomputed
+// reciprocal replaces each division; the subtraction is the reference's, (bound - e) * (1/d), so d == 0 gives the
+// same +-inf / NaN pattern as its division (a fused b*rd - e*rd would turn inf - inf into NaN and lose the slab).
+// OCT < 8: bit a of OCT is the sign bit of direction component a for every lane of the wave, which tells at compile
+// time which of the two planes of an axis is entered first: half of the min/max operations disappear (they run at
+// half the rate of a multiply or add on this hardware).  OCT == 8: lanes differ, min/max per axis.
+// The exit distance is widened by a few units in the last place (the reciprocal form is that far off), which keeps
+// a ray that passes exactly through a box corner or edge (a shared vertex of a mesh) from slipping between boxes.
+// tmin returns the entry distance, not below lo.
+template <int OCT>
+RT_HD bool slab_fast(const float* b, V3 o, V3 rd, float lo, float lim, float& tmin) {
+    float tn, tf;
+    if (OCT < 8) {
+        const float nx = (b[(OCT & 1) ? 3 : 0] - o.x) * rd.x, fx = (b[(OCT & 1) ? 0 : 3] - o.x) * rd.x;
+        const float ny = (b[(OCT & 2) ? 4 : 1] - o.y) * rd.y, fy = (b[(OCT & 2) ? 1 : 4] - o.y) * rd.y;
+        const float nz = (b[(OCT & 4) ? 5 : 2] - o.z) * rd.z, fz = (b[(OCT & 4) ? 2 : 5] - o.z) * rd.z;
+        tn = fmaxf(fmaxf(nx, ny), nz);
+        tf = fminf(fminf(fx, fy), fz);
+    } else {
+        const float t1 = (b[0] - o.x) * rd.x, t2 = (b[3] - o.x) * rd.x;
+        const float t3 = (b[1] - o.y) * rd.y, t4 = (b[4] - o.y) * rd.y;
+        const float t5 = (b[2] - o.z) * rd.z, t6 = (b[5] - o.z) * rd.z;
+        tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    }
+    tmin = fmaxf(tn, lo);
+    return !(tmin > fminf(tf * 1.000001f, lim));
+}
+
+// Bounds the pruning traversal hands to slab_fast.
+// lim, "this subtree starts beyond the best hit so far": the triangle distances it is compared with are rounded
+// results of a different formula than the box distances, so equal or almost equal hits in different leaves (a ray
+// through a shared vertex or edge) must all be looked at: the reference picks among them by (t, tie rank), which
+// needs every candidate.  lo, "this box ends before the ray's interval starts": a ray that leaves a flat surface
+// skips that surface's own boxes at once instead of descending to the leaves around its origin.
 RT_HD float prune_limit(float best_t) { return best_t * 1.00001f; }
+RT_HD float entry_limit(float t0) { return fmaxf(t0 * 0.99999f, 0.f); }
+
+// Work counters of the counting kernels: steps of this lane, or (profiling build, -DRT_COUNT_WAVE_STEPS) steps of the
+// wave - only the first active lane counts, so the sum over lanes * 64 against the per-lane sum is the lane
+// utilisation of the loop.
+#if defined(RT_COUNT_WAVE_STEPS) && !defined(RT_HOST_EMULATION)
+#define RT_COUNT_STEP(c) do { if ((int)threadIdx.x == __builtin_amdgcn_readfirstlane((int)threadIdx.x)) ++(c); } while (0)
+#else
+#define RT_COUNT_STEP(c) ++(c)
+#endif
 
 #ifndef RT_STACK
 #define RT_STACK 96       // deepest tree the traversal accepts (checked when the scene is created)
@@ -256,18 +283,19 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
 // One inner node: tests both children and returns the next reference to visit (the far child is pushed when both are
 // hit; RT_NONE when the stack is empty).  The sixteen node words are passed as scalars so that the same code serves
 // words held in vector registers and words held in scalar registers (a node the whole wave fetched once).
-template <bool EXACT>
+template <bool EXACT, int OCT>
 RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8,
                         float b9, float b10, float b11, int32_t r0, int32_t r1, int32_t r2, int32_t r3, StackLds& st,
-                        V3 o, V3 d, V3 rd, float lim) {
+                        V3 o, V3 d, V3 rd, float lo, float lim) {
     const float lb[6] = {b0, b1, b2, b3, b4, b5};
     const float rb[6] = {b6, b7, b8, b9, b10, b11};
     // the reference's own leaves when its exact box tests are asked for, the refined ones otherwise
     const int32_t lref = EXACT ? r0 : r2, rref = EXACT ? r1 : r3;
     float tl, tr;
-    bool hl = slab<EXACT>(lb, o, d, rd, tl);
-    bool hr = slab<EXACT>(rb, o, d, rd, tr) && (rref != RT_NONE);
-    if (!EXACT) { hl = hl && !(tl > lim); hr = hr && !(tr > lim); }
+    bool hl, hr;
+    if (EXACT) { hl = slab_exact(lb, o, d, tl); hr = slab_exact(rb, o, d, tr); }
+    else { hl = slab_fast<OCT>(lb, o, rd, lo, lim, tl); hr = slab_fast<OCT>(rb, o, rd, lo, lim, tr); }
+    hr = hr && (rref != RT_NONE);
     if (hl && hr) {
         const bool swap = !EXACT && tr < tl;
         st.push(swap ? lref : rref);
@@ -285,21 +313,22 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
 // best t so far are skipped and the nearer child is visited first.
 // Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
 // so that the lanes of a wave run the same kind of work together.
-template <bool ANY, bool EXACT>
-RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
-                    uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+template <bool ANY, bool EXACT, int OCT>
+RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
+                        uint32_t* n_nodes, uint32_t* n_tris) {
     best.t = INFINITY; best.tri = -1; best.rank = INT32_MAX; best.beta = 0.f; best.gamma = 0.f;
     V3 rd = v3(0, 0, 0);
     if (!EXACT) rd = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    const float lo = entry_limit(t0);
     st.sp = 0;
     int32_t cur = 0;
     bool found = false;
     for (;;) {
         // ---- descend until a leaf is reached (cur < 0) or nothing is left (cur == RT_NONE)
         while (cur >= 0) {
-            if (n_nodes) ++*n_nodes;
+            if (n_nodes) RT_COUNT_STEP(*n_nodes);
             const float lim = EXACT ? INFINITY : (ANY ? t1 : prune_limit(best.t));
-            RT_NODE_STEP(EXACT, sc.nodes, cur, st, o, d, rd, lim);
+            RT_NODE_STEP(EXACT, OCT, sc.nodes, cur, st, o, d, rd, lo, lim);
         }
         if (cur == RT_NONE) break;
         // ---- one leaf: a run of consecutive triangles
@@ -311,7 +340,7 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
                 const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
                 RT_KEEP4(p0); RT_KEEP4(p1); RT_KEEP4(p2);
                 if (r == 0) run = RT_F2I(EXACT ? p0.w : p1.w);
-                if (n_tris) ++*n_tris;
+                if (n_tris) RT_COUNT_STEP(*n_tris);
                 float t, beta, gamma;
                 if (!tri_test(p0, p1, p2, o, d, t0, ANY ? t1 : fminf(t1, best.t), t, beta, gamma)) continue;
                 // a NaN t (0/0 on a zero-area triangle) passes every comparison of the test; it is never a hit here
@@ -326,6 +355,38 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
         cur = st.pop();
     }
     return found;
+}
+
+#ifdef RT_HOST_EMULATION
+static bool rt_emu_mixed_octants = false;   // host build: take the code path of a wave whose lanes differ in octant
+#endif
+
+// Picks the traversal specialised for the wave's direction octant (see slab_fast).
+template <bool ANY, bool EXACT>
+RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
+                    uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+    if (EXACT) return traverse_oct<ANY, true, 8>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+    int oct = (int)(((uint32_t)RT_F2I(d.x) >> 31) | (((uint32_t)RT_F2I(d.y) >> 31) << 1) | (((uint32_t)RT_F2I(d.z) >> 31) << 2));
+    // a zero component makes (bound - e) * (1/d) a NaN where the ray's origin lies exactly in a box plane; the
+    // reference's fmin/fmax then answer by their NaN-dropping order, which only the min/max form reproduces
+    if (d.x == 0.f || d.y == 0.f || d.z == 0.f) oct = 8;
+#ifdef RT_HOST_EMULATION
+    if (rt_emu_mixed_octants) oct = 8;
+#else
+    const int uoct = __builtin_amdgcn_readfirstlane(oct);
+    oct = (__builtin_amdgcn_ballot_w64(oct != uoct) == 0) ? uoct : 8;
+#endif
+    switch (oct) {
+        case 0: return traverse_oct<ANY, false, 0>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 1: return traverse_oct<ANY, false, 1>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 2: return traverse_oct<ANY, false, 2>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 3: return traverse_oct<ANY, false, 3>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 4: return traverse_oct<ANY, false, 4>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 5: return traverse_oct<ANY, false, 5>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 6: return traverse_oct<ANY, false, 6>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 7: return traverse_oct<ANY, false, 7>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        default: return traverse_oct<ANY, false, 8>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+    }
 }
 
 // src/geometry.cpp:297-306: interpolated unit normal of the hit

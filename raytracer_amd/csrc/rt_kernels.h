@@ -55,12 +55,14 @@ RT_HD float4 mk4(V3 a, float w) { float4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w
 RT_HD V3 point_at(V3 e, V3 d, float t) { return vadd(e, vscale(d, t)); }    // src/ray.cpp:32-35
 
 // ---------------------------------------------------------------------------------------------- generate
-// Level-0 nodes are stored tile by tile: 4x4 pixels x spp^2 samples are consecutive, so that the 64 lanes of a wave
-// work on a compact patch of the image (rays that stay together longer) instead of a one-pixel-high strip.
+// Level-0 nodes are stored tile by tile: 4x4 pixels x spp^2 samples are consecutive, and inside a tile 2x2 pixels are,
+// so that the 64 lanes of a wave work on a compact patch of the image (rays that stay together longer) instead of a
+// one-pixel-high strip - whether a wave takes 64 nodes (nearest hit) or 64 / (spr + 1) nodes (light rays).
 // Slot of pixel (px, py) of the band (px = column in the rect, py = row in the band), times spp^2, + sample.
 RT_HD int64_t pixel_slot(const RenderParams& P, int px, int py) {
     const int tiles_x = (P.rw + 3) >> 2;
-    return ((int64_t)((py >> 2) * tiles_x + (px >> 2)) << 4) + ((py & 3) << 2) + (px & 3);
+    const int q = (px & 1) | ((py & 1) << 1) | ((px & 2) << 1) | ((py & 2) << 2);   // 2x2 blocks of 2x2 pixels
+    return ((int64_t)((py >> 2) * tiles_x + (px >> 2)) << 4) + q;
 }
 
 // Node g of the implicit level 0: g = slot * spp^2 + sample (src/render_thread.cpp:57-94).
@@ -71,7 +73,7 @@ RT_HD NodeIn primary_node(const DScene& sc, const RenderParams& P, int64_t g) {
     const int tiles_x = (P.rw + 3) >> 2;
     const int64_t tile = slot >> 4;
     const int q = (int)(slot & 15);
-    const int px = (int)(tile % tiles_x) * 4 + (q & 3), py = (int)(tile / tiles_x) * 4 + (q >> 2);
+    const int px = (int)(tile % tiles_x) * 4 + ((q & 1) | ((q >> 1) & 2)), py = (int)(tile / tiles_x) * 4 + (((q >> 1) & 1) | ((q >> 2) & 2));
     NodeIn n;
     n.o = v3p(sc.cam.pos); n.d = v3(0, 0, 0); n.key = 0; n.weight = 1.f;
     n.refraci = RT_F2I(1.f); n.comp = (int32_t)g;
@@ -149,25 +151,40 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
 }
 
 // ------------------------------------------------------------------------------------------------ shadow
-// w = node * n_lights + light: the lane traces the spr jittered rays and the exact ray toward one light
-// (src/render_thread.cpp:146-161) and stores how many reached it.  Returns the number of rays traced.
+// Item w = node * n_lights + light: the spr jittered rays and the exact ray toward one light from the hit point of
+// the node's companion shadow ray (src/render_thread.cpp:146-161); unocc[w] = how many of them reached the light.
+struct ShadowItem { V3 p, exact; uint32_t key; int li; };
+
+// false: the shadow-type ray missed, nothing is traced and the record stays stale
+RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, int64_t w, ShadowItem& it) {
+    const int64_t i = w / sc.n_lights;
+    it.li = (int)(w - i * sc.n_lights);
+    const int comp = L.implicit ? (int)i : L.meta[i].w;
+    if (L.tri[comp] < 0) return false;
+    const NodeIn cin = node_in(sc, P, L, comp);
+    it.p = point_at(cin.o, cin.d, L.hit[comp].w);
+    it.key = L.implicit ? cin.key : (uint32_t)RT_F2I(L.org[i].w);
+    it.exact = vnorm(light_dir(sc.lights[it.li], it.p, P, it.key, SITE_SH_LIGHT, (uint32_t)it.li));   // Ray ctor normalises
+    return true;
+}
+
+// ray k of the item (k < spr: jittered copy, k == spr: the exact direction); true when it reaches the light
+template <bool EXACT>
+RT_HD bool shadow_ray(const DScene& sc, const RenderParams& P, const ShadowItem& it, StackLds& st, int k,
+                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+    const V3 d = (k < P.spr) ? split_dir(it.exact, P.ray_eps, P, it.key, SITE_SH_SPLIT, (uint32_t)it.li, (uint32_t)k) : it.exact;
+    HitRec h;
+    return !traverse<true, EXACT>(sc, st, it.p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris);
+}
+
+// The whole item in one lane (what the kernel spreads over spr+1 lanes).  Returns the number of rays traced.
 template <bool EXACT>
 RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t w,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    const int64_t i = w / sc.n_lights;
-    const int li = (int)(w - i * sc.n_lights);
-    const int comp = L.implicit ? (int)i : L.meta[i].w;
-    if (L.tri[comp] < 0) return 0;                                  // the shadow-type ray missed: record stays stale
-    const NodeIn cin = node_in(sc, P, L, comp);
-    const V3 p = point_at(cin.o, cin.d, L.hit[comp].w);
-    const uint32_t key = L.implicit ? cin.key : (uint32_t)RT_F2I(L.org[i].w);
-    const V3 exact = vnorm(light_dir(sc.lights[li], p, P, key, SITE_SH_LIGHT, (uint32_t)li));   // Ray ctor normalises
+    ShadowItem it;
+    if (!shadow_item(sc, P, L, w, it)) return 0;
     uint32_t unocc = 0;
-    for (int k = 0; k <= P.spr; ++k) {
-        const V3 d = (k < P.spr) ? split_dir(exact, P.ray_eps, P, key, SITE_SH_SPLIT, (uint32_t)li, (uint32_t)k) : exact;
-        HitRec h;
-        if (!traverse<true, EXACT>(sc, st, p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris)) ++unocc;
-    }
+    for (int k = 0; k <= P.spr; ++k) unocc += shadow_ray<EXACT>(sc, P, it, st, k, n_nodes, n_tris) ? 1u : 0u;
     L.unocc[w] = unocc;
     return P.spr + 1;
 }

@@ -38,14 +38,31 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Lev
     add_work<COUNT>(work, nn, nt);
 }
 
+// One lane per light ray: the spr+1 rays of an item sit in consecutive lanes (a wave takes 64 / (spr+1) items and
+// leaves the remaining lanes idle), so the lanes of a wave trace rays of few neighbouring origins and the wave is done
+// when its slowest ray is - a lane that looped over the item's rays would wait for the slowest lane once per ray.
+// The item's count is the population count of the wave's "reached the light" mask over the item's lanes.
 template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, unsigned long long* traced, unsigned long long* work) {
-    const int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int R = P.spr + 1, per_wave = 64 / R;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int sub = lane / R, k = lane - sub * R;
+    const int64_t w = wave * per_wave + sub;
     uint32_t did = 0, nn = 0, nt = 0;
+    bool reached = false;
     RT_DECLARE_STACK(st);
-    if (w < n_items) did = (uint32_t)body_shadow<EXACT>(sc, P, L, st, w, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
-    did = wave_sum(did);
-    if ((threadIdx.x & 63) == 0 && did) atomicAdd(traced, (unsigned long long)did);
+    ShadowItem it;
+    if (sub < per_wave && w < n_items && shadow_item(sc, P, L, w, it)) {
+        did = 1;
+        reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    }
+    const unsigned long long mask = __ballot(reached);
+    if (did && k == 0) L.unocc[w] = (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull));
+    if (traced) {
+        did = wave_sum(did);
+        if (lane == 0 && did) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE], (unsigned long long)did);
+    }
     add_work<COUNT>(work, nn, nt);
 }
 
@@ -91,7 +108,8 @@ void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Le
 void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,
                    unsigned long long* work, hipStream_t s) {
     if (n_items <= 0) return;
-    const unsigned g = blocks(n_items);
+    const int64_t per_wave = 64 / (P.spr + 1);
+    const unsigned g = blocks((n_items + per_wave - 1) / per_wave * 64);
     if (work) {
         if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, work);
         else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, work);

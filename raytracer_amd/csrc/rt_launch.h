@@ -10,7 +10,9 @@ struct LevelSet { Level lv[RT_MAX_LEVELS]; };
 // work (may be NULL): work[0] += inner nodes fetched, work[1] += triangles tested
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
                    unsigned long long* work, hipStream_t s);
-// *traced += light rays traced
+// traced (may be NULL): light rays traced, accumulated in RT_TRACED_SLOTS counters RT_TRACED_STRIDE apart (one
+// address would serialise the per-wave atomics in one L2 channel); the caller sums the slots
+enum { RT_TRACED_SLOTS = 64, RT_TRACED_STRIDE = 16 };
 void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,
                    unsigned long long* work, hipStream_t s);
 void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s);
