@@ -78,6 +78,7 @@ void free_level(LevelBuf& b) {
     if (b.L.dir) (void)hipFree(b.L.dir);
     if (b.L.meta) (void)hipFree(b.L.meta);
     if (b.L.hit) (void)hipFree(b.L.hit);
+    if (b.L.pos) (void)hipFree(b.L.pos);
     if (b.L.tri) (void)hipFree(b.L.tri);
     if (b.L.kids) (void)hipFree(b.L.kids);
     if (b.L.aux) (void)hipFree(b.L.aux);
@@ -98,6 +99,7 @@ int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit) {
         HIP_TRY(hipMalloc((void**)&b.L.meta, cap * sizeof(int4)));
     }
     HIP_TRY(hipMalloc((void**)&b.L.hit, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&b.L.pos, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&b.L.tri, cap * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&b.L.kids, cap * sizeof(int2)));
     HIP_TRY(hipMalloc((void**)&b.L.aux, cap * sizeof(float)));
@@ -288,6 +290,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     P.eps = o->eps; P.ray_eps = o->ray_eps; P.jitter = o->jitter_mode; P.seed = o->seed;
     P.row_stride = o->row_stride; P.row_band = o->row_band; P.row_phase = o->row_phase;
     P.can_spawn = sc->any_spawning_material ? 1 : 0;
+    rt::set_divisors(P, sc->n_lights);
     {   // src/render_thread.cpp:34-40 (PI is the float 3.1415926, :3)
         const float aspect_ratio = o->height / (float)o->width;
         const float d = sc->d.cam.near_clip;
@@ -367,6 +370,8 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
             ++lvl;
             if (kids == 0) break;
             if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");
+            if (kids * (int64_t)std::max(nl, 1) >= ((int64_t)1 << 31))
+                return fail(RT_ERR_UNSUPPORTED, "a level of the ray tree exceeds 2^31 light-ray items; render a smaller rectangle");
             rc = ensure_level(sc->lv[lvl], kids, nl, false);
             if (rc != RT_OK) return rc;
             rt::launch_spawn(sc->d, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);

@@ -28,6 +28,7 @@ struct Level {
     int4* meta;        // x parent index in the previous level (-1 at level 0), y = type | depth<<8 | rank<<16,
                        // z = bits(refraci), w = index (this level) of the node whose ray the companion shadow ray repeats
     float4* hit;       // xyz unit normal at the hit, w = t
+    float4* pos;       // xyz hit point e + t d (src/ray.cpp:32-35), w = bits(path key); written where the ray hit
     int32_t* tri;      // triangle position (traversal order) or -1
     int2* kids;        // x = first child in the next level (-1: none), y = number of children
     float* aux;        // Schlick term r_theta of a refractive spawn
@@ -67,13 +68,11 @@ RT_HD int64_t pixel_slot(const RenderParams& P, int px, int py) {
 
 // Node g of the implicit level 0: g = slot * spp^2 + sample (src/render_thread.cpp:57-94).
 RT_HD NodeIn primary_node(const DScene& sc, const RenderParams& P, int64_t g) {
-    const int spp2 = P.spp * P.spp;
-    const int64_t slot = g / spp2;
-    const int s = (int)(g - slot * spp2);
-    const int tiles_x = (P.rw + 3) >> 2;
-    const int64_t tile = slot >> 4;
+    const uint32_t slot = fdiv((uint32_t)g, P.div_spp2);
+    const int s = (int)((uint32_t)g - slot * (uint32_t)(P.spp * P.spp));
+    const uint32_t tile = slot >> 4, tile_y = fdiv(tile, P.div_tiles_x), tile_x = tile - tile_y * (uint32_t)((P.rw + 3) >> 2);
     const int q = (int)(slot & 15);
-    const int px = (int)(tile % tiles_x) * 4 + ((q & 1) | ((q >> 1) & 2)), py = (int)(tile / tiles_x) * 4 + (((q >> 1) & 1) | ((q >> 2) & 2));
+    const int px = (int)tile_x * 4 + ((q & 1) | ((q >> 1) & 2)), py = (int)tile_y * 4 + (((q >> 1) & 1) | ((q >> 2) & 2));
     NodeIn n;
     n.o = v3p(sc.cam.pos); n.d = v3(0, 0, 0); n.key = 0; n.weight = 1.f;
     n.refraci = RT_F2I(1.f); n.comp = (int32_t)g;
@@ -136,6 +135,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     }
     const V3 n = hit_normal(sc, h);
     L.hit[i] = mk4(n, h.t);
+    L.pos[i] = mk4(point_at(in.o, d, h.t), RT_I2F((int32_t)in.key));
     L.tri[i] = h.tri;
     if (!P.can_spawn) return 0;
     const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
@@ -157,13 +157,13 @@ struct ShadowItem { V3 p, exact; uint32_t key; int li; };
 
 // false: the shadow-type ray missed, nothing is traced and the record stays stale
 RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, int64_t w, ShadowItem& it) {
-    const int64_t i = w / sc.n_lights;
-    it.li = (int)(w - i * sc.n_lights);
+    const uint32_t i = fdiv((uint32_t)w, P.div_lights);
+    it.li = (int)((uint32_t)w - i * (uint32_t)sc.n_lights);
     const int comp = L.implicit ? (int)i : L.meta[i].w;
     if (L.tri[comp] < 0) return false;
-    const NodeIn cin = node_in(sc, P, L, comp);
-    it.p = point_at(cin.o, cin.d, L.hit[comp].w);
-    it.key = L.implicit ? cin.key : (uint32_t)RT_F2I(L.org[i].w);
+    const float4 pk = L.pos[comp];
+    it.p = f4v(pk);
+    it.key = L.implicit ? (uint32_t)RT_F2I(pk.w) : (uint32_t)RT_F2I(L.org[i].w);
     it.exact = vnorm(light_dir(sc.lights[it.li], it.p, P, it.key, SITE_SH_LIGHT, (uint32_t)it.li));   // Ray ctor normalises
     return true;
 }

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     const int R = P.spr + 1, per_wave = 64 / R;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const int sub = lane / R, k = lane - sub * R;
+    const int sub = (int)fdiv((uint32_t)lane, P.div_rays), k = lane - sub * R;
     const int64_t w = wave * per_wave + sub;
     uint32_t did = 0, nn = 0, nt = 0;
     bool reached = false;
