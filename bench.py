@@ -165,31 +165,46 @@ def roofline(tracer, opt, W, H, dev, stream):
         _, st = tracer.render_rect(opt, 0, 0, W, H, out=out, stats=True, stream=stream)
         ext.append(st.ms_extend); sha.append(st.ms_shadow); shade.append(st.ms_shade)
     ms_ext, ms_sha, ms_shade = float(np.mean(ext)), float(np.mean(sha)), float(np.mean(shade))
-    # per ray: the node's queue records it reads/writes + 64 B per inner node fetched + 48 B per triangle tested
-    # (+ 36 B of vertex normals for a nearest hit); DESIGN.md "Kernels" states these figures
-    # queue records: a nearest-hit ray writes hit (16 B) + triangle (4 B) and reads 36 B of normals on a hit; one
-    # (node, light) item of spr+1 light rays reads triangle + hit (20 B) and writes its count (4 B)
-    b_ext = cs.rays_closest * (20 + 36) + 64 * cs.nodes_extend + 48 * cs.tris_extend
+    # algorithmic bytes: 64 B per inner node fetched + 48 B per triangle tested, plus the queue records: a nearest-hit
+    # ray writes normal+t (16 B), triangle (4 B) and, on a hit, the hit point (16 B) after reading 36 B of vertex
+    # normals; one (node, light) item of spr+1 light rays reads triangle + hit point (20 B) and writes its count (4 B)
+    b_ext = cs.rays_closest * (20 + 36 + 16) + 64 * cs.nodes_extend + 48 * cs.tris_extend
     b_sha = cs.rays_any // (opt.spr + 1) * 24 + 64 * cs.nodes_shadow + 48 * cs.tris_shadow
     if ms_sha >= ms_ext:
         name, b, ms, rays, nn, nt = "k_shadow (any-hit light rays)", b_sha, ms_sha, cs.rays_any, cs.nodes_shadow, cs.tris_shadow
     else:
         name, b, ms, rays, nn, nt = "k_extend (nearest hit)", b_ext, ms_ext, cs.rays_closest, cs.nodes_extend, cs.tris_extend
     achieved = b / (ms * 1e-3) / 1e9
-    traffic = None
+    traffic = valu = util = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(name.split()[0])
+            prof = json.load(open(tpath))
+            key = name.split()[0]
+            traffic = prof.get(key)
+            valu = prof.get("valu_insts_per_launch", {}).get(key)
+            util = prof.get("lane_utilisation", {}).get(key)
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "launch_ms": round(ms, 4), "rays_per_launch": int(rays), "algorithmic_bytes_per_launch": int(b),
-            "nodes_per_ray": round(nn / max(rays, 1), 2), "tris_per_ray": round(nt / max(rays, 1), 2),
-            "ms_extend": round(ms_ext, 4), "ms_shadow": round(ms_sha, 4), "ms_replay": round(ms_shade, 4),
-            "note": "algorithmic bytes are mostly served by L2 (the tree is ~1 MB), so achieved may exceed HBM peak; "
-                    "traffic = measured HBM bytes per launch"}
+    out = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "launch_ms": round(ms, 4), "rays_per_launch": int(rays), "algorithmic_bytes_per_launch": int(b),
+           "nodes_per_ray": round(nn / max(rays, 1), 2), "tris_per_ray": round(nt / max(rays, 1), 2),
+           "ms_extend": round(ms_ext, 4), "ms_shadow": round(ms_sha, 4), "ms_replay": round(ms_shade, 4),
+           "note": "algorithmic bytes are node and triangle fetches, which L1/L2 serve (the tree is ~1 MB), so achieved "
+                   "can exceed the HBM peak; traffic = HBM bytes per launch from the PMC passes in profiles/. The kernel "
+                   "is bound by vector-instruction issue, see valu_issue"}
+    if traffic:
+        out["hbm_measured_GBps"] = round(traffic / (ms * 1e-3) / 1e9, 1)
+    if valu:
+        # 1024 SIMDs at 2.4 GHz; a SIMD issues one wave64 instruction per 2 cycles (mul/add/mov) or 4 (min/max/compare/
+        # fma/SGPR operand): profiles/r01_f_valu_issue_costs.txt
+        simd_cycles = ms * 1e-3 * 2.4e9 * 1024
+        out["valu_issue"] = {"insts_per_launch": valu, "simd_cycles_per_inst": round(simd_cycles / valu, 2),
+                             "lane_utilisation": util,
+                             "note": "instruction count from profiles/ (SQ_INSTS_VALU of the same workload); 2-4 cycles "
+                                     "per instruction means the vector ALUs are issuing nearly all the time"}
+    return out
 
 
 def cpu_baseline(scene, opt, gpu_ms):
