@@ -77,6 +77,7 @@ void free_level(LevelBuf& b) {
     if (b.L.org) (void)hipFree(b.L.org);
     if (b.L.dir) (void)hipFree(b.L.dir);
     if (b.L.meta) (void)hipFree(b.L.meta);
+    if (b.L.rec) (void)hipFree(b.L.rec);
     if (b.L.hit) (void)hipFree(b.L.hit);
     if (b.L.pos) (void)hipFree(b.L.pos);
     if (b.L.tri) (void)hipFree(b.L.tri);
@@ -98,12 +99,16 @@ int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit) {
         HIP_TRY(hipMalloc((void**)&b.L.dir, cap * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&b.L.meta, cap * sizeof(int4)));
     }
-    HIP_TRY(hipMalloc((void**)&b.L.hit, cap * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&b.L.pos, cap * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&b.L.tri, cap * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&b.L.kids, cap * sizeof(int2)));
-    HIP_TRY(hipMalloc((void**)&b.L.aux, cap * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&b.L.unocc, cap * lights * sizeof(uint32_t)));
+    if (implicit) {
+        HIP_TRY(hipMalloc((void**)&b.L.hit, cap * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&b.L.pos, cap * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&b.L.tri, cap * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void**)&b.L.kids, cap * sizeof(int2)));
+        HIP_TRY(hipMalloc((void**)&b.L.aux, cap * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&b.L.unocc, cap * lights * sizeof(uint8_t)));
+    } else {
+        HIP_TRY(hipMalloc((void**)&b.L.rec, cap * sizeof(rt::NodeRec)));
+    }
     b.cap = cap; b.lights = lights;
     return RT_OK;
 }
@@ -304,7 +309,14 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     const int nl = sc->n_lights;
 
     // band height: a level-0 budget of samples; scenes that can spawn get a smaller one because levels multiply
-    int64_t budget = sc->any_spawning_material ? (int64_t)1 << 21 : (int64_t)1 << 24;
+    int64_t budget = (int64_t)1 << 24;
+    if (sc->any_spawning_material) {
+        // levels below the first can hold many times the band's samples (a mirror hit spawns spr+1 rays per bounce);
+        // a band must still be large enough to fill the GPU when there are many samples per pixel
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        budget = (free_b >= ((size_t)96 << 30)) ? (int64_t)1 << 23 : (int64_t)1 << 21;
+    }
     int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
     if (band_rows < rh) band_rows = std::max(4, band_rows & ~3);       // whole 4-row tiles per band
 

@@ -22,21 +22,49 @@ enum { RAY_SHADOW = 0, RAY_REFLECT = 1, RAY_REFRACTIVE = 2,      // src/ray.h:10
        RAY_NONE = 3 };                                          // padding slot of a partly covered pixel tile
 enum { RT_MAX_LEVELS = 20 };
 
+// Everything the kernels after the nearest-hit search need to know about a node, in ONE 64-byte record: the replay
+// walks a pixel's ray tree node by node, and neighbouring lanes are at unrelated nodes below the first level, so every
+// separately stored field costs a memory sector of its own.
+struct alignas(64) NodeRec {
+    float px, py, pz; uint32_t key;   // hit point e + t d (src/ray.cpp:32-35); path key of the node's ray
+    float nx, ny, nz, t;              // unit normal at the hit; t
+    int32_t kid_base;                 // first child in the next level (written by spawn)
+    int32_t flags;                    // type | depth << 8 | rank << 16 | REC_SAME_MEDIUM; byte 3 = number of children
+    float weight;                     // src/ray.h:36
+    int32_t tri;                      // triangle position (traversal order) or -1
+    float aux;                        // Schlick term r_theta of a refractive spawn
+    int32_t comp;                     // node (this level) whose ray the companion shadow ray repeats
+    uint8_t unocc[8];                 // per light: light rays that reached it, out of spr+1 (written by shadow, only
+                                      // where the companion shadow ray hit)
+};
+enum { REC_SAME_MEDIUM = 1 << 21 };   // the ray travels in the hit material's own medium (refraci == refractivity)
+
 struct Level {
     float4* org;       // xyz ray origin, w = bits(path key)
     float4* dir;       // xyz ray direction, w = weight (src/ray.h:36)
     int4* meta;        // x parent index in the previous level (-1 at level 0), y = type | depth<<8 | rank<<16,
                        // z = bits(refraci), w = index (this level) of the node whose ray the companion shadow ray repeats
+    NodeRec* rec;      // results of a stored level
+    // results of the implicit level 0, one array per field: there neighbouring lanes ARE neighbouring nodes, so
+    // separate arrays are read and written fully coalesced and fields a scene never uses cost nothing
     float4* hit;       // xyz unit normal at the hit, w = t
-    float4* pos;       // xyz hit point e + t d (src/ray.cpp:32-35), w = bits(path key); written where the ray hit
-    int32_t* tri;      // triangle position (traversal order) or -1
-    int2* kids;        // x = first child in the next level (-1: none), y = number of children
-    float* aux;        // Schlick term r_theta of a refractive spawn
-    uint32_t* unocc;   // [n][n_lights] light rays that reached the light, out of spr+1 (written only where the
-                       // node's companion shadow ray hit)
+    float4* pos;       // xyz hit point, w = bits(path key)
+    int32_t* tri;      // triangle position or -1
+    int2* kids;        // first child in the next level, number of children (scenes that can spawn only)
+    float* aux;        // Schlick term of a refractive spawn
+    uint8_t* unocc;    // [n][n_lights]
     int32_t implicit;  // 1: level 0 - org/dir/meta are not stored; node g IS the primary ray of slot g / spp^2,
                        // sample g % spp^2, and is recomputed wherever it is needed (cheaper than 48 B per sample)
 };
+
+// ---- access to a node's results in either layout
+RT_HD int32_t res_tri(const Level& L, int64_t i) { return L.implicit ? L.tri[i] : L.rec[i].tri; }
+RT_HD float4 res_pos(const Level& L, int64_t i) { return L.implicit ? L.pos[i] : *reinterpret_cast<const float4*>(&L.rec[i].px); }
+RT_HD float4 res_hit(const Level& L, int64_t i) { return L.implicit ? L.hit[i] : *reinterpret_cast<const float4*>(&L.rec[i].nx); }
+RT_HD void set_kids(const Level& L, int64_t i, int32_t base, int cnt) {
+    if (L.implicit) { int2 kd; kd.x = base; kd.y = cnt; L.kids[i] = kd; }
+    else { L.rec[i].kid_base = base; reinterpret_cast<uint8_t*>(&L.rec[i].flags)[3] = (uint8_t)cnt; }
+}
 
 // What the kernels need to know about a node's ray.
 struct NodeIn {
@@ -117,37 +145,54 @@ RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
     return r_theta;
 }
 
+RT_HD int4 mk_i4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
 // returns the number of children this node will spawn
 template <bool EXACT>
 RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t i,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     const NodeIn in = node_in(sc, P, L, i);
-    if (P.can_spawn) { int2 kd; kd.x = -1; kd.y = 0; L.kids[i] = kd; }
     HitRec h;
     bool hit = false;
     const V3 d = in.d;
     if (meta_type(in.packed) != RAY_NONE)
         hit = traverse<false, EXACT>(sc, st, in.o, d, P.eps, INFINITY, h, n_nodes, n_tris);
-    if (!hit) {
-        L.hit[i] = mk4(v3(0, 0, 0), INFINITY);
-        L.tri[i] = -1;
-        return 0;
+    float r_theta = 0.f;
+    int kids = 0, flags = in.packed;
+    float4 pk = mk4(v3(0, 0, 0), 0.f), hn = mk4(v3(0, 0, 0), INFINITY);
+    int kind = 0;
+    if (hit) {
+        const V3 n = hit_normal(sc, h);
+        pk = mk4(point_at(in.o, d, h.t), RT_I2F((int32_t)in.key));
+        hn = mk4(n, h.t);
+        const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
+        kind = M.kind;
+        if (RT_I2F(in.refraci) == M.refractivity) flags |= REC_SAME_MEDIUM;
+        const int depth = meta_depth(in.packed);
+        if (P.can_spawn && depth > 0 && M.kind == 2) kids = P.spr + 1;
+        if (P.can_spawn && depth > 0 && M.kind == 3) {
+            V3 td;
+            r_theta = refract_dir(d, n, RT_I2F(in.refraci), M.refractivity, td);
+            kids = (r_theta <= 0) ? 1 : 2;                              // src/render_thread.cpp:345
+        }
     }
-    const V3 n = hit_normal(sc, h);
-    L.hit[i] = mk4(n, h.t);
-    L.pos[i] = mk4(point_at(in.o, d, h.t), RT_I2F((int32_t)in.key));
-    L.tri[i] = h.tri;
-    if (!P.can_spawn) return 0;
-    const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
-    const int depth = meta_depth(in.packed);
-    if (depth > 0 && M.kind == 2) return P.spr + 1;
-    if (depth > 0 && M.kind == 3) {
-        V3 td;
-        const float r_theta = refract_dir(d, n, RT_I2F(in.refraci), M.refractivity, td);
-        L.aux[i] = r_theta;
-        return (r_theta <= 0) ? 1 : 2;                              // src/render_thread.cpp:345
+    if (L.implicit) {
+        L.tri[i] = hit ? h.tri : -1;
+        if (P.can_spawn) { int2 kd; kd.x = -1; kd.y = 0; L.kids[i] = kd; }
+        if (hit) {
+            L.hit[i] = hn; L.pos[i] = pk;
+            if (kind == 3) L.aux[i] = r_theta;
+        }
+    } else {
+        NodeRec* R = L.rec + i;
+        if (hit) {
+            *reinterpret_cast<float4*>(&R->px) = pk;
+            *reinterpret_cast<float4*>(&R->nx) = hn;
+        }
+        *reinterpret_cast<int4*>(&R->kid_base) = mk_i4(-1, flags, RT_F2I(in.weight), hit ? h.tri : -1);
+        *reinterpret_cast<int4*>(&R->aux) = mk_i4(RT_F2I(r_theta), in.comp, 0, 0);
     }
-    return 0;
+    return kids;
 }
 
 // ------------------------------------------------------------------------------------------------ shadow
@@ -160,12 +205,18 @@ RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, 
     const uint32_t i = fdiv((uint32_t)w, P.div_lights);
     it.li = (int)((uint32_t)w - i * (uint32_t)sc.n_lights);
     const int comp = L.implicit ? (int)i : L.meta[i].w;
-    if (L.tri[comp] < 0) return false;
-    const float4 pk = L.pos[comp];
+    if (res_tri(L, comp) < 0) return false;
+    const float4 pk = res_pos(L, comp);
     it.p = f4v(pk);
     it.key = L.implicit ? (uint32_t)RT_F2I(pk.w) : (uint32_t)RT_F2I(L.org[i].w);
     it.exact = vnorm(light_dir(sc.lights[it.li], it.p, P, it.key, SITE_SH_LIGHT, (uint32_t)it.li));   // Ray ctor normalises
     return true;
+}
+
+RT_HD void store_unocc(const DScene& sc, const RenderParams& P, const Level& L, int64_t w, uint32_t unocc) {
+    if (L.implicit) { L.unocc[w] = (uint8_t)unocc; return; }
+    const uint32_t i = fdiv((uint32_t)w, P.div_lights);
+    L.rec[i].unocc[(uint32_t)w - i * (uint32_t)sc.n_lights] = (uint8_t)unocc;
 }
 
 // ray k of the item (k < spr: jittered copy, k == spr: the exact direction); true when it reaches the light
@@ -185,25 +236,23 @@ RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, S
     if (!shadow_item(sc, P, L, w, it)) return 0;
     uint32_t unocc = 0;
     for (int k = 0; k <= P.spr; ++k) unocc += shadow_ray<EXACT>(sc, P, it, st, k, n_nodes, n_tris) ? 1u : 0u;
-    L.unocc[w] = unocc;
+    store_unocc(sc, P, L, w, unocc);
     return P.spr + 1;
 }
 
 // ------------------------------------------------------------------------------------------------- spawn
 RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
-    const int tri = L.tri[i];
+    const int tri = res_tri(L, i);
     if (tri < 0) return;
     const NodeIn in = node_in(sc, P, L, i);
     const int depth = meta_depth(in.packed);
     const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
     if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
     const V3 o = in.o, d = in.d;
-    const float4 hn = L.hit[i];
-    const V3 n = f4v(hn);
-    const float t = hn.w;
+    const V3 n = f4v(res_hit(L, i));
     const uint32_t key = in.key;
     const float weight = in.weight;
-    const V3 p = point_at(o, d, t);
+    const V3 p = f4v(res_pos(L, i));
     // mirror direction, src/linmath.h:59-65
     const float pp = 2.f * vdot(d, n);
     const V3 rd = v3(d.x - pp * n.x, d.y - pp * n.y, d.z - pp * n.z);
@@ -218,8 +267,7 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
             int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = in.refraci; cm.w = (int)(base + P.spr);
             N.meta[base + k] = cm;
         }
-        int2 kd; kd.x = (int)base; kd.y = cnt;
-        L.kids[i] = kd;
+        set_kids(L, i, (int32_t)base, cnt);
     } else {                                                        // src/render_thread.cpp:318-394
         const float refraci = RT_I2F(in.refraci);
         V3 td = v3(0, 0, 0);
@@ -242,8 +290,7 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
             int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFRACTIVE, d_rt, 1); cm.z = zi; cm.w = (int)(base + 1);
             N.meta[base + 1] = cm;
         }
-        int2 kd; kd.x = (int)base; kd.y = cnt;
-        L.kids[i] = kd;
+        set_kids(L, i, (int32_t)base, cnt);
     }
 }
 
@@ -309,25 +356,47 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
         for (;;) {
             // ---- pop one render ray: node i of level lvl with colour state (cc, contrib, tpc)
             const Level& L = lv[lvl];
-            const NodeIn in = node_in(sc, P, L, i);
-            const int type = meta_type(in.packed), depth = meta_depth(in.packed);
-            const float weight = in.weight;
+            // kid_base, flags (type, depth, children), weight, triangle; then the rest of what this node needs
+            int4 head; float aux = 0.f; int comp_tri;
+            const uint8_t* un;
+            if (L.implicit) {
+                head.w = L.tri[i];
+                head.y = meta_pack(RAY_REFLECT, P.D, 0); head.z = RT_F2I(1.f); head.x = -1;
+                if (P.can_spawn && head.w >= 0) { const int2 kd = L.kids[i]; head.x = kd.x; head.y |= kd.y << 24; }
+                comp_tri = head.w;                       // the companion repeats the node's own ray
+                un = L.unocc + i * sc.n_lights;
+            } else {
+                const NodeRec* R = L.rec + i;
+                head = *reinterpret_cast<const int4*>(&R->kid_base);
+                aux = R->aux;
+                comp_tri = L.rec[R->comp].tri;
+                un = R->unocc;
+            }
+            const int type = meta_type(head.y), depth = meta_depth(head.y), n_kids = (int)((uint32_t)head.y >> 24);
+            const float weight = RT_I2F(head.z);
+            const int tri = head.w;
             // its companion shadow-type ray pops just before it (:134-171)
-            if (L.tri[in.comp] >= 0)
+            if (comp_tri >= 0)
                 for (int li = 0; li < sc.n_lights; ++li) {
-                    float sh_frac = (float)L.unocc[i * sc.n_lights + li];    // +1 per light ray that hit nothing
+                    float sh_frac = (float)un[li];                                // +1 per light ray that hit nothing
                     sh_frac /= (float)(P.spr + 1);
                     shadow_rec[li] = sh_frac;
                 }
-            const int tri = L.tri[i];
             bool draw = false, has_kids = false;
             V3 c = v3(0, 0, 0);
             if (tri >= 0) {
                 const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
-                const float4 hn = L.hit[i];
+                const float4 hn = res_hit(L, i);
                 const V3 n = f4v(hn);
-                const V3 p = point_at(in.o, in.d, hn.w);
-                const uint32_t key = in.key;
+                V3 p; uint32_t key;
+                if (L.implicit) {
+                    // this kernel waits for memory: recomputing the primary ray is cheaper than reading the hit point
+                    const NodeIn in = primary_node(sc, P, i);
+                    p = point_at(in.o, in.d, hn.w); key = in.key;
+                } else {
+                    const float4 pk = res_pos(L, i);
+                    p = f4v(pk); key = (uint32_t)RT_F2I(pk.w);
+                }
                 const bool use_refl = (M.kind == 2 || M.kind == 3), use_refr = (M.kind == 3);
                 if (!use_refl) {                                                 // :187-200
                     V3 add = apply_shade(sc, P, M, p, n, shadow_rec, key);
@@ -342,25 +411,23 @@ RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv,
                     self = vscale(self, contrib);
                     if (depth == P.D) cc = self; else cc = vadd(cc, self);
                     tpc += contrib;
-                    const int2 kd = L.kids[i];
                     RFrame& F = fr[lvl];
-                    F.base = kd.x; F.count = kd.y; F.next = kd.y - 1; F.refr = 0; F.r_theta = 0.f;
+                    F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 0; F.r_theta = 0.f;
                     F.c = cc; F.contrib = contrib; F.tpc = tpc;
-                    has_kids = kd.y > 0;
+                    has_kids = n_kids > 0;
                 } else if (depth <= 0) {                                         // :286-293, :400-406
                     c = cc; draw = true;
                 } else {                                                         // :300-397
                     V3 c_add;
-                    if (RT_I2F(in.refraci) == M.refractivity) {
+                    if (L.implicit ? (1.f == M.refractivity) : ((head.y & REC_SAME_MEDIUM) != 0)) {
                         c_add.x = M.transp[0] * expf(-M.transp[0] * hn.w);
                         c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
                         c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);
                     } else c_add = v3(1, 1, 1);
-                    const int2 kd = L.kids[i];
                     RFrame& F = fr[lvl];
-                    F.base = kd.x; F.count = kd.y; F.next = kd.y - 1; F.refr = 1; F.r_theta = L.aux[i];
+                    F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 1; F.r_theta = L.implicit ? L.aux[i] : aux;
                     F.c = vmul(cc, c_add); F.contrib = 1.f; F.tpc = 0.f;
-                    has_kids = kd.y > 0;
+                    has_kids = n_kids > 0;
                 }
             } else {                                                             // :414-430
                 if ((type == RAY_REFLECT && depth < P.D) || (type == RAY_REFRACTIVE && depth < Dr)) { c = cc; draw = true; }

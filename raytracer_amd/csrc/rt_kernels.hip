@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
         reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     }
     const unsigned long long mask = __ballot(reached);
-    if (did && k == 0) L.unocc[w] = (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull));
+    if (did && k == 0) store_unocc(sc, P, L, w, (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull)));
     if (traced) {
         did = wave_sum(did);
         if (lane == 0 && did) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE], (unsigned long long)did);
