@@ -37,9 +37,14 @@ struct LevelBuf {
     rt::Level L{};
     int64_t cap = 0;
     int lights = 0;
+    bool draws = false;    // carries the arrays of the two-pass replay
 };
 
 }  // namespace
+
+#ifndef RT_TWO_PASS_MIN_SAMPLES
+#define RT_TWO_PASS_MIN_SAMPLES 16
+#endif
 
 enum { RT_N_COUNTERS = 16 + rt::RT_TRACED_SLOTS * rt::RT_TRACED_STRIDE * 2 };   // u32 words of the counter block
 
@@ -84,13 +89,15 @@ void free_level(LevelBuf& b) {
     if (b.L.kids) (void)hipFree(b.L.kids);
     if (b.L.aux) (void)hipFree(b.L.aux);
     if (b.L.unocc) (void)hipFree(b.L.unocc);
+    if (b.L.draw) (void)hipFree(b.L.draw);
+    if (b.L.first) (void)hipFree(b.L.first);
     b = LevelBuf();
 }
 
 // implicit: level 0, whose rays are recomputed instead of stored (no org/dir/meta arrays)
-int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit) {
+int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit, bool draws) {
     lights = std::max(lights, 1);
-    if (b.cap >= n && b.lights >= lights) return RT_OK;
+    if (b.cap >= n && b.lights >= lights && (b.draws || !draws)) return RT_OK;
     const int64_t cap = std::max<int64_t>(n + n / 4, 1024);
     free_level(b);
     b.L.implicit = implicit ? 1 : 0;
@@ -109,7 +116,11 @@ int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit) {
     } else {
         HIP_TRY(hipMalloc((void**)&b.L.rec, cap * sizeof(rt::NodeRec)));
     }
-    b.cap = cap; b.lights = lights;
+    if (draws) {
+        HIP_TRY(hipMalloc((void**)&b.L.draw, cap * sizeof(rt::DrawRec)));
+        if (implicit) HIP_TRY(hipMalloc((void**)&b.L.first, cap * sizeof(int2)));
+    }
+    b.cap = cap; b.lights = lights; b.draws = draws;
     return RT_OK;
 }
 
@@ -320,6 +331,9 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
     if (band_rows < rh) band_rows = std::max(4, band_rows & ~3);       // whole 4-row tiles per band
 
+    // replay in two passes (a lane per sample, then a lane per pixel) where a pixel's samples are many and its ray
+    // trees can be deep; one fused pass otherwise (it moves fewer bytes)
+    const bool two_pass = sc->any_spawning_material && spp2 >= RT_TWO_PASS_MIN_SAMPLES;
     const bool out_dev = is_device_ptr(rgb_out);
     float* d_out = rgb_out;
     if (!out_dev) {
@@ -344,7 +358,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         const int64_t n_pix = (int64_t)rows * rw;
         const int64_t n_real = n_pix * spp2;
         int64_t n = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;   // level-0 slots incl. tile padding
-        int rc = ensure_level(sc->lv[0], n, nl, true);
+        int rc = ensure_level(sc->lv[0], n, nl, true, two_pass);
         if (rc != RT_OK) return rc;
         P.band_y0 = y0 + by; P.band_rows = rows;
         int lvl = 0;
@@ -384,7 +398,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
             if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");
             if (kids * (int64_t)std::max(nl, 1) >= ((int64_t)1 << 31))
                 return fail(RT_ERR_UNSUPPORTED, "a level of the ray tree exceeds 2^31 light-ray items; render a smaller rectangle");
-            rc = ensure_level(sc->lv[lvl], kids, nl, false);
+            rc = ensure_level(sc->lv[lvl], kids, nl, false, two_pass);
             if (rc != RT_OK) return rc;
             rt::launch_spawn(sc->d, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);
             n = kids;
@@ -393,7 +407,9 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         rt::LevelSet ls{};
         for (int q = 0; q < lvl; ++q) ls.lv[q] = sc->lv[q].L;
         if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
-        rt::launch_replay(sc->d, P, ls, n_pix, d_out + (int64_t)by * rw * 3, s);
+        const int64_t n0 = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;
+        if (two_pass) rt::launch_shade_sum(sc->d, P, ls, n0, n_pix, d_out + (int64_t)by * rw * 3, s);
+        else rt::launch_replay(sc->d, P, ls, n_pix, d_out + (int64_t)by * rw * 3, s);
         if (timing) {
             HIP_TRY(hipEventRecord(sc->ev[1], s));
             HIP_TRY(hipEventSynchronize(sc->ev[1]));

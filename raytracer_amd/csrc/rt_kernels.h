@@ -39,6 +39,9 @@ struct alignas(64) NodeRec {
 };
 enum { REC_SAME_MEDIUM = 1 << 21 };   // the ray travels in the hit material's own medium (refraci == refractivity)
 
+// What one popped render ray adds to its pixel (src/render_thread.cpp:434-438) and which node draws next.
+struct alignas(32) DrawRec { float cx, cy, cz, w; int32_t next_lvl, next_idx, pad0, pad1; };
+
 struct Level {
     float4* org;       // xyz ray origin, w = bits(path key)
     float4* dir;       // xyz ray direction, w = weight (src/ray.h:36)
@@ -53,6 +56,9 @@ struct Level {
     int2* kids;        // first child in the next level, number of children (scenes that can spawn only)
     float* aux;        // Schlick term of a refractive spawn
     uint8_t* unocc;    // [n][n_lights]
+    // two-pass replay only (see replay_sample): what each drawing node adds to its pixel, chained in pop order
+    struct DrawRec* draw;   // per node of this level
+    int2* first;            // level 0: (level, node) of the first drawing node of the sample's tree, (-1, -1) if none
     int32_t implicit;  // 1: level 0 - org/dir/meta are not stored; node g IS the primary ray of slot g / spp^2,
                        // sample g % spp^2, and is recomputed wherever it is needed (cheaper than 48 B per sample)
 };
@@ -338,116 +344,163 @@ struct RFrame {
     V3 c; float contrib, tpc; // colour state handed to the children (src/render_thread.cpp:245-248, :348, :367-382)
 };
 
+// One sample: walks the ray tree under level-0 node g in the reference's pop order (the newest pushed ray pops
+// first) and hands every drawn colour to emit(level, node, colour, weight).
+// The per-pixel shadow record (src/render_thread.cpp:134-171) is refreshed by the level-0 node before anything below
+// it is shaded (a primary ray that hit nothing has no children), so its value on entry never matters and samples can
+// be replayed independently of each other; the ORDER of the additions to the pixel is what must be kept.
+template <class Emit>
+RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* lv, int64_t g, Emit& emit) {
+    const float Dr = (float)P.Dr;
+    float shadow_rec[8];
+    for (int q = 0; q < 8; ++q) shadow_rec[q] = 1.f;
+    RFrame fr[RT_MAX_LEVELS];
+    int lvl = 0;
+    int64_t i = g;
+    V3 cc = v3(0, 0, 0);
+    float contrib = 1.f, tpc = 0.f;
+    for (;;) {
+        // ---- pop one render ray: node i of level lvl with colour state (cc, contrib, tpc)
+        const Level& L = lv[lvl];
+        // kid_base, flags (type, depth, children), weight, triangle; then the rest of what this node needs
+        int4 head; float aux = 0.f; int comp_tri;
+        const uint8_t* un;
+        if (L.implicit) {
+            head.w = L.tri[i];
+            head.y = meta_pack(RAY_REFLECT, P.D, 0); head.z = RT_F2I(1.f); head.x = -1;
+            if (P.can_spawn && head.w >= 0) { const int2 kd = L.kids[i]; head.x = kd.x; head.y |= kd.y << 24; }
+            comp_tri = head.w;                       // the companion repeats the node's own ray
+            un = L.unocc + i * sc.n_lights;
+        } else {
+            const NodeRec* R = L.rec + i;
+            head = *reinterpret_cast<const int4*>(&R->kid_base);
+            aux = R->aux;
+            comp_tri = L.rec[R->comp].tri;
+            un = R->unocc;
+        }
+        const int type = meta_type(head.y), depth = meta_depth(head.y), n_kids = (int)((uint32_t)head.y >> 24);
+        const float weight = RT_I2F(head.z);
+        const int tri = head.w;
+        // its companion shadow-type ray pops just before it (:134-171)
+        if (comp_tri >= 0)
+            for (int li = 0; li < sc.n_lights; ++li) {
+                float sh_frac = (float)un[li];                                // +1 per light ray that hit nothing
+                sh_frac /= (float)(P.spr + 1);
+                shadow_rec[li] = sh_frac;
+            }
+        bool draw = false, has_kids = false;
+        V3 c = v3(0, 0, 0);
+        if (tri >= 0) {
+            const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
+            const float4 hn = res_hit(L, i);
+            const V3 n = f4v(hn);
+            V3 p; uint32_t key;
+            if (L.implicit) {
+                // this kernel waits for memory: recomputing the primary ray is cheaper than reading the hit point
+                const NodeIn in = primary_node(sc, P, i);
+                p = point_at(in.o, in.d, hn.w); key = in.key;
+            } else {
+                const float4 pk = res_pos(L, i);
+                p = f4v(pk); key = (uint32_t)RT_F2I(pk.w);
+            }
+            const bool use_refl = (M.kind == 2 || M.kind == 3), use_refr = (M.kind == 3);
+            if (!use_refl) {                                                 // :187-200
+                V3 add = apply_shade(sc, P, M, p, n, shadow_rec, key);
+                if (contrib != 1) add = vscale(add, 1 - tpc);
+                cc = vadd(cc, add);
+                c = cc; draw = true;
+            } else if (depth > 0 && !use_refr) {                             // :207-283
+                float prev = M.reflectivity;
+                contrib = 1 - prev;
+                for (int q = depth; q < P.D; ++q) { contrib = prev * (1 - M.reflectivity); prev = prev - contrib; }
+                V3 self = apply_shade(sc, P, M, p, n, shadow_rec, key);
+                self = vscale(self, contrib);
+                if (depth == P.D) cc = self; else cc = vadd(cc, self);
+                tpc += contrib;
+                RFrame& F = fr[lvl];
+                F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 0; F.r_theta = 0.f;
+                F.c = cc; F.contrib = contrib; F.tpc = tpc;
+                has_kids = n_kids > 0;
+            } else if (depth <= 0) {                                         // :286-293, :400-406
+                c = cc; draw = true;
+            } else {                                                         // :300-397
+                V3 c_add;
+                if (L.implicit ? (1.f == M.refractivity) : ((head.y & REC_SAME_MEDIUM) != 0)) {
+                    c_add.x = M.transp[0] * expf(-M.transp[0] * hn.w);
+                    c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
+                    c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);
+                } else c_add = v3(1, 1, 1);
+                RFrame& F = fr[lvl];
+                F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 1; F.r_theta = L.implicit ? L.aux[i] : aux;
+                F.c = vmul(cc, c_add); F.contrib = 1.f; F.tpc = 0.f;
+                has_kids = n_kids > 0;
+            }
+        } else {                                                             // :414-430
+            if ((type == RAY_REFLECT && depth < P.D) || (type == RAY_REFRACTIVE && depth < Dr)) { c = cc; draw = true; }
+        }
+        if (draw) emit(lvl, i, c, weight);                                   // :434-438
+        // ---- next ray to pop: the newest pushed one
+        if (!has_kids) {
+            --lvl;
+            while (lvl >= 0 && fr[lvl].next < 0) --lvl;
+            if (lvl < 0) break;
+        }
+        const RFrame& F = fr[lvl];
+        const int k = fr[lvl].next--;
+        i = F.base + k;
+        cc = F.c; contrib = F.contrib; tpc = F.tpc;
+        if (F.refr && F.count == 2) cc = vscale(cc, k == 0 ? F.r_theta : 1 - F.r_theta);   // :368, :382
+        ++lvl;
+    }
+}
+
+// adds to the pixel at once (src/rasterizer.cpp:92-96)
+struct EmitSum {
+    V3 sum, wsum;
+    RT_HDM void operator()(int, int64_t, V3 c, float weight) { sum = vadd(sum, c); wsum = vadd(wsum, v3(weight, weight, weight)); }
+};
+
 // One pixel: pl = row_in_band * rw + column_in_rect.  Writes rgb_out[pl] = sum(colours) / sum(weights).
 RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out) {
     const int spp2 = P.spp * P.spp;
     const int64_t slot = pixel_slot(P, (int)(pl % P.rw), (int)(pl / P.rw));
-    const float Dr = (float)P.Dr;
-    float shadow_rec[8];
-    for (int q = 0; q < 8; ++q) shadow_rec[q] = 1.f;
-    V3 sum = v3(0, 0, 0), wsum = v3(0, 0, 0);
-    RFrame fr[RT_MAX_LEVELS];
+    EmitSum e; e.sum = v3(0, 0, 0); e.wsum = v3(0, 0, 0);
     // push order of src/render_thread.cpp:57-109 is sample 0 first, so the last sample pops first
+    for (int s = spp2 - 1; s >= 0; --s) replay_sample(sc, P, lv, slot * spp2 + s, e);
+    rgb_out[pl * 3 + 0] = e.sum.x / e.wsum.x;
+    rgb_out[pl * 3 + 1] = e.sum.y / e.wsum.y;
+    rgb_out[pl * 3 + 2] = e.sum.z / e.wsum.z;
+}
+
+// ---- the same in two passes, for scenes with many samples per pixel and deep ray trees: one lane per SAMPLE shades
+// (64 or more times the lanes, each with a short walk), storing what every drawing node adds and chaining those nodes
+// in pop order; then one lane per pixel only adds the stored colours in that order.
+struct EmitChain {
+    const Level* lv; int64_t g;
+    int plvl; int64_t pidx; V3 pc; float pw;      // the previous drawing node, written once its successor is known
+    RT_HDM void flush(int nl, int64_t ni) {
+        if (plvl < 0) { int2 f; f.x = nl; f.y = (int)ni; lv[0].first[g] = f; return; }
+        DrawRec d; d.cx = pc.x; d.cy = pc.y; d.cz = pc.z; d.w = pw; d.next_lvl = nl; d.next_idx = (int32_t)ni; d.pad0 = 0; d.pad1 = 0;
+        lv[plvl].draw[pidx] = d;
+    }
+    RT_HDM void operator()(int l, int64_t i, V3 c, float weight) { flush(l, i); plvl = l; pidx = i; pc = c; pw = weight; }
+};
+RT_HD void body_shade(const DScene& sc, const RenderParams& P, const Level* lv, int64_t g) {
+    EmitChain e; e.lv = lv; e.g = g; e.plvl = -1; e.pidx = 0; e.pc = v3(0, 0, 0); e.pw = 0.f;
+    if (lv[0].tri[g] >= 0) replay_sample(sc, P, lv, g, e);    // a primary ray that hit nothing draws nothing
+    e.flush(-1, -1);    // closes the chain, or marks the sample as drawing nothing
+}
+RT_HD void body_sum(const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out) {
+    const int spp2 = P.spp * P.spp;
+    const int64_t slot = pixel_slot(P, (int)(pl % P.rw), (int)(pl / P.rw));
+    V3 sum = v3(0, 0, 0), wsum = v3(0, 0, 0);
     for (int s = spp2 - 1; s >= 0; --s) {
-        int lvl = 0;
-        int64_t i = slot * spp2 + s;
-        V3 cc = v3(0, 0, 0);
-        float contrib = 1.f, tpc = 0.f;
-        for (;;) {
-            // ---- pop one render ray: node i of level lvl with colour state (cc, contrib, tpc)
-            const Level& L = lv[lvl];
-            // kid_base, flags (type, depth, children), weight, triangle; then the rest of what this node needs
-            int4 head; float aux = 0.f; int comp_tri;
-            const uint8_t* un;
-            if (L.implicit) {
-                head.w = L.tri[i];
-                head.y = meta_pack(RAY_REFLECT, P.D, 0); head.z = RT_F2I(1.f); head.x = -1;
-                if (P.can_spawn && head.w >= 0) { const int2 kd = L.kids[i]; head.x = kd.x; head.y |= kd.y << 24; }
-                comp_tri = head.w;                       // the companion repeats the node's own ray
-                un = L.unocc + i * sc.n_lights;
-            } else {
-                const NodeRec* R = L.rec + i;
-                head = *reinterpret_cast<const int4*>(&R->kid_base);
-                aux = R->aux;
-                comp_tri = L.rec[R->comp].tri;
-                un = R->unocc;
-            }
-            const int type = meta_type(head.y), depth = meta_depth(head.y), n_kids = (int)((uint32_t)head.y >> 24);
-            const float weight = RT_I2F(head.z);
-            const int tri = head.w;
-            // its companion shadow-type ray pops just before it (:134-171)
-            if (comp_tri >= 0)
-                for (int li = 0; li < sc.n_lights; ++li) {
-                    float sh_frac = (float)un[li];                                // +1 per light ray that hit nothing
-                    sh_frac /= (float)(P.spr + 1);
-                    shadow_rec[li] = sh_frac;
-                }
-            bool draw = false, has_kids = false;
-            V3 c = v3(0, 0, 0);
-            if (tri >= 0) {
-                const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
-                const float4 hn = res_hit(L, i);
-                const V3 n = f4v(hn);
-                V3 p; uint32_t key;
-                if (L.implicit) {
-                    // this kernel waits for memory: recomputing the primary ray is cheaper than reading the hit point
-                    const NodeIn in = primary_node(sc, P, i);
-                    p = point_at(in.o, in.d, hn.w); key = in.key;
-                } else {
-                    const float4 pk = res_pos(L, i);
-                    p = f4v(pk); key = (uint32_t)RT_F2I(pk.w);
-                }
-                const bool use_refl = (M.kind == 2 || M.kind == 3), use_refr = (M.kind == 3);
-                if (!use_refl) {                                                 // :187-200
-                    V3 add = apply_shade(sc, P, M, p, n, shadow_rec, key);
-                    if (contrib != 1) add = vscale(add, 1 - tpc);
-                    cc = vadd(cc, add);
-                    c = cc; draw = true;
-                } else if (depth > 0 && !use_refr) {                             // :207-283
-                    float prev = M.reflectivity;
-                    contrib = 1 - prev;
-                    for (int q = depth; q < P.D; ++q) { contrib = prev * (1 - M.reflectivity); prev = prev - contrib; }
-                    V3 self = apply_shade(sc, P, M, p, n, shadow_rec, key);
-                    self = vscale(self, contrib);
-                    if (depth == P.D) cc = self; else cc = vadd(cc, self);
-                    tpc += contrib;
-                    RFrame& F = fr[lvl];
-                    F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 0; F.r_theta = 0.f;
-                    F.c = cc; F.contrib = contrib; F.tpc = tpc;
-                    has_kids = n_kids > 0;
-                } else if (depth <= 0) {                                         // :286-293, :400-406
-                    c = cc; draw = true;
-                } else {                                                         // :300-397
-                    V3 c_add;
-                    if (L.implicit ? (1.f == M.refractivity) : ((head.y & REC_SAME_MEDIUM) != 0)) {
-                        c_add.x = M.transp[0] * expf(-M.transp[0] * hn.w);
-                        c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
-                        c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);
-                    } else c_add = v3(1, 1, 1);
-                    RFrame& F = fr[lvl];
-                    F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 1; F.r_theta = L.implicit ? L.aux[i] : aux;
-                    F.c = vmul(cc, c_add); F.contrib = 1.f; F.tpc = 0.f;
-                    has_kids = n_kids > 0;
-                }
-            } else {                                                             // :414-430
-                if ((type == RAY_REFLECT && depth < P.D) || (type == RAY_REFRACTIVE && depth < Dr)) { c = cc; draw = true; }
-            }
-            if (draw) {                                                          // :434-438 and src/rasterizer.cpp:92-96
-                sum = vadd(sum, c);
-                wsum = vadd(wsum, v3(weight, weight, weight));
-            }
-            // ---- next ray to pop: the newest pushed one
-            if (!has_kids) {
-                --lvl;
-                while (lvl >= 0 && fr[lvl].next < 0) --lvl;
-                if (lvl < 0) break;
-            }
-            const RFrame& F = fr[lvl];
-            const int k = fr[lvl].next--;
-            i = F.base + k;
-            cc = F.c; contrib = F.contrib; tpc = F.tpc;
-            if (F.refr && F.count == 2) cc = vscale(cc, k == 0 ? F.r_theta : 1 - F.r_theta);   // :368, :382
-            ++lvl;
+        int2 at = lv[0].first[slot * spp2 + s];
+        while (at.x >= 0) {
+            const DrawRec d = lv[at.x].draw[at.y];
+            sum = vadd(sum, v3(d.cx, d.cy, d.cz));
+            wsum = vadd(wsum, v3(d.w, d.w, d.w));
+            at.x = d.next_lvl; at.y = d.next_idx;
         }
     }
     rgb_out[pl * 3 + 0] = sum.x / wsum.x;

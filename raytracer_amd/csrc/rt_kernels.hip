@@ -76,6 +76,16 @@ __global__ __launch_bounds__(BLOCK) void k_replay(DScene sc, RenderParams P, Lev
     if (pl < n_pixels) body_replay(sc, P, ls.lv, pl, rgb_out);
 }
 
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, RenderParams P, LevelSet ls, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g < n) body_shade(sc, P, ls.lv, g);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sum(RenderParams P, LevelSet ls, int64_t n_pixels, float* rgb_out) {
+    const int64_t pl = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pl < n_pixels) body_sum(P, ls.lv, pl, rgb_out);
+}
+
 template <bool ANY, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float* org, const float* dir, float t0, float t1, int64_t n,
                                                  float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct) {
@@ -123,6 +133,10 @@ void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const
 }
 void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_pixels, float* rgb_out, hipStream_t s) {
     if (n_pixels > 0) k_replay<<<blocks(n_pixels), BLOCK, 0, s>>>(sc, P, ls, n_pixels, rgb_out);
+}
+void launch_shade_sum(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_nodes0, int64_t n_pixels, float* rgb_out, hipStream_t s) {
+    if (n_nodes0 > 0) k_shade<<<blocks(n_nodes0), BLOCK, 0, s>>>(sc, P, ls, n_nodes0);
+    if (n_pixels > 0) k_sum<<<blocks(n_pixels), BLOCK, 0, s>>>(P, ls, n_pixels, rgb_out);
 }
 void launch_trace(bool any, bool exact, const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t n,
                   float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct, hipStream_t s) {

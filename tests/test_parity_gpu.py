@@ -100,6 +100,10 @@ CASES = {
     "glass_balls": (lambda: scenes.glass_balls(10), dict(width=80, height=48, hfov=54.5, spp=2, spr=4, max_bounce=3, max_refrac_bounce=5, eps=1e-3), False),
     "spp1_spr0": (lambda: scenes.bunny(phong_surroundings=True), dict(width=64, height=36, hfov=60, spp=1, spr=0, max_bounce=1), True),
     "spp3": (lambda: scenes.bunny(), dict(width=48, height=27, hfov=54.43, spp=3, spr=4, max_bounce=3), True),
+    # 16 samples per pixel on scenes whose materials spawn rays: the replay runs in two passes (a lane per sample
+    # shades, a lane per pixel adds in pop order)
+    "mirror_room_spp4": (lambda: scenes.mirror_room(5, sphere_res=6), dict(width=40, height=24, hfov=60, spp=4, spr=2, max_bounce=3, eps=1e-3, ray_eps=0.01), True),
+    "glass_balls_spp4": (lambda: scenes.glass_balls(8), dict(width=40, height=24, hfov=54.5, spp=4, spr=2, max_bounce=2, max_refrac_bounce=4, eps=1e-3), False),
 }
 
 
