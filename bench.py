@@ -142,7 +142,7 @@ def main():
     }
 
     if rank == 0:
-        result["roofline"] = roofline(tracer, opt, W, H, dev, stream)
+        result["roofline"] = roofline(tracer, opt, W, H, dev, stream, args.workload)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, opt, ms_per_step)
         print(json.dumps(result), flush=True)
@@ -151,7 +151,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(tracer, opt, W, H, dev, stream):
+def roofline(tracer, opt, W, H, dev, stream, workload):
     """Dominant kernel of the frame: its algorithmic bytes per launch over its measured duration (HIP events recorded
     by the library around the kernel, on the stream it runs on)."""
     out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
@@ -180,6 +180,8 @@ def roofline(tracer, opt, W, H, dev, stream):
     if os.path.exists(tpath):
         try:
             prof = json.load(open(tpath))
+            if prof.get("workload") != workload:      # counters were collected on another workload
+                prof = {}
             key = name.split()[0]
             traffic = prof.get(key)
             valu = prof.get("valu_insts_per_launch", {}).get(key)

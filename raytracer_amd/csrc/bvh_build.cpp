@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -39,6 +40,9 @@ inline void box_union(Box& a, const Box& b) {                 // src/geometry.cp
 struct Built { int32_t ref, ref_fine; Box box; int depth; };
 
 constexpr int RT_FINE_LEAF = 4;
+#ifndef RT_SAH_LEAF
+#define RT_SAH_LEAF 4       // most triangles in a leaf of the surface-area-heuristic tree
+#endif
 
 inline void set_node(Node64& n, const Built& L, const Built& R) {
     memcpy(n.lbox, L.box.lo, 12); memcpy(n.lbox + 3, L.box.hi, 12);
@@ -237,6 +241,256 @@ bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, 
     }
     out->nodes[0] = entry;
     out->max_depth = depth;
+    return true;
+}
+
+namespace {
+
+// ---- surface-area-heuristic build -----------------------------------------------------------------------------
+struct SahRef { Box b; float c[3]; int32_t id; };   // triangle box, box centre, global triangle id
+
+inline float half_area(const Box& b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct SahBuilder {
+    enum { BINS = 16, LEAF = RT_SAH_LEAF, MAX_SAH_DEPTH = 64 };
+    std::vector<SahRef> refs;
+    const rt_mesh_desc* meshes;
+    std::vector<int32_t> mesh_of, first_of;   // per mesh: first global id; per global id lookups go through these
+    std::vector<int32_t> rank_of;             // by global triangle id
+    FlatScene* out;
+
+    void emit_tri(int32_t id, int run) {
+        const int mi = (int)(std::upper_bound(first_of.begin(), first_of.end(), id) - first_of.begin()) - 1;
+        const int t = id - first_of[mi];
+        const float* a = meshes[mi].pos + (size_t)t * 9; const float* b = a + 3; const float* c = a + 6;
+        Tri48 q;
+        q.ax = a[0]; q.ay = a[1]; q.az = a[2]; q.run = run;
+        q.abx = a[0] - b[0]; q.aby = a[1] - b[1]; q.abz = a[2] - b[2]; q.run_fine = run;
+        q.acx = a[0] - c[0]; q.acy = a[1] - c[1]; q.acz = a[2] - c[2]; q.rank = rank_of[id];
+        out->tris.push_back(q);
+        TriInfo fi; fi.id = id; fi.mesh = mi;
+        out->info.push_back(fi);
+        const float* nn = meshes[mi].nrm + (size_t)t * 9;
+        out->nrm.insert(out->nrm.end(), nn, nn + 9);
+    }
+
+    Built build(int lo, int hi, int depth) {
+        const int n = hi - lo;
+        Built r; r.depth = 0;
+        r.box = refs[lo].b;
+        for (int k = lo + 1; k < hi; ++k) box_union(r.box, refs[k].b);
+        if (n <= LEAF) {
+            r.ref = r.ref_fine = ~(int32_t)out->tris.size();
+            for (int k = 0; k < n; ++k) emit_tri(refs[lo + k].id, n - k);
+            out->n_leaves++;
+            return r;
+        }
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = lo; k < hi; ++k)
+            for (int i = 0; i < 3; ++i) { cmin[i] = fminf(cmin[i], refs[k].c[i]); cmax[i] = fmaxf(cmax[i], refs[k].c[i]); }
+        int best_axis = -1, best_bin = 0; float best_cost = INFINITY;
+        if (depth < MAX_SAH_DEPTH)
+            for (int ax = 0; ax < 3; ++ax) {
+                const float ext = cmax[ax] - cmin[ax];
+                if (!(ext > 0.f) || !std::isfinite(ext)) continue;
+                const float scale = BINS / ext;
+                Box bb[BINS]; int cnt[BINS];
+                for (int q = 0; q < BINS; ++q) { cnt[q] = 0; for (int i = 0; i < 3; ++i) { bb[q].lo[i] = INFINITY; bb[q].hi[i] = -INFINITY; } }
+                for (int k = lo; k < hi; ++k) {
+                    int q = (int)((refs[k].c[ax] - cmin[ax]) * scale);
+                    q = q < 0 ? 0 : (q >= BINS ? BINS - 1 : q);
+                    ++cnt[q]; box_union(bb[q], refs[k].b);
+                }
+                float right_area[BINS]; int right_cnt[BINS];
+                Box acc; for (int i = 0; i < 3; ++i) { acc.lo[i] = INFINITY; acc.hi[i] = -INFINITY; }
+                int c = 0;
+                for (int q = BINS - 1; q > 0; --q) {
+                    if (cnt[q]) box_union(acc, bb[q]);
+                    c += cnt[q]; right_cnt[q] = c; right_area[q] = c ? half_area(acc) : 0.f;
+                }
+                for (int i = 0; i < 3; ++i) { acc.lo[i] = INFINITY; acc.hi[i] = -INFINITY; }
+                c = 0;
+                for (int q = 0; q < BINS - 1; ++q) {                 // split after bin q
+                    if (cnt[q]) box_union(acc, bb[q]);
+                    c += cnt[q];
+                    if (c == 0 || right_cnt[q + 1] == 0) continue;
+                    const float cost = half_area(acc) * c + right_area[q + 1] * right_cnt[q + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = q; }
+                }
+            }
+        int mid;
+        if (best_axis >= 0) {
+            const float scale = BINS / (cmax[best_axis] - cmin[best_axis]);
+            const float c0 = cmin[best_axis];
+            const int ax = best_axis, bbin = best_bin;
+            SahRef* m = std::partition(refs.data() + lo, refs.data() + hi, [=](const SahRef& x) {
+                int q = (int)((x.c[ax] - c0) * scale);
+                q = q < 0 ? 0 : (q >= BINS ? BINS - 1 : q);
+                return q <= bbin;
+            });
+            mid = (int)(m - refs.data());
+        } else {
+            // all centres coincide (or the tree got too deep): halve by count along the widest axis
+            int ax = 0;
+            for (int i = 1; i < 3; ++i) if (cmax[i] - cmin[i] > cmax[ax] - cmin[ax]) ax = i;
+            mid = lo + n / 2;
+            std::nth_element(refs.begin() + lo, refs.begin() + mid, refs.begin() + hi, [ax](const SahRef& x, const SahRef& y) {
+                return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.id < y.id);
+            });
+        }
+        if (mid <= lo || mid >= hi) mid = lo + n / 2;
+        const int32_t idx = (int32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        const Built L = build(lo, mid, depth + 1);
+        const Built R = build(mid, hi, depth + 1);
+        set_node(out->nodes[idx], L, R);
+        r.ref = r.ref_fine = idx;
+        r.depth = 1 + std::max(L.depth, R.depth);
+        return r;
+    }
+};
+
+// Top tree over already built subtrees (one per mesh), also by binned surface-area heuristic; an item weighs as many
+// triangles as its subtree holds.
+struct TopItem { Built b; float c[3]; int n; };
+
+Built build_top_sah(FlatScene* out, std::vector<TopItem>& it, int lo, int hi) {
+    if (hi - lo == 1) return it[lo].b;
+    enum { BINS = 16 };
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = lo; k < hi; ++k)
+        for (int i = 0; i < 3; ++i) { cmin[i] = fminf(cmin[i], it[k].c[i]); cmax[i] = fmaxf(cmax[i], it[k].c[i]); }
+    int best_axis = -1, best_bin = 0; float best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ++ax) {
+        const float ext = cmax[ax] - cmin[ax];
+        if (!(ext > 0.f) || !std::isfinite(ext)) continue;
+        const float scale = BINS / ext;
+        Box bb[BINS]; int64_t cnt[BINS]; int items[BINS];
+        for (int q = 0; q < BINS; ++q) { cnt[q] = 0; items[q] = 0; for (int i = 0; i < 3; ++i) { bb[q].lo[i] = INFINITY; bb[q].hi[i] = -INFINITY; } }
+        for (int k = lo; k < hi; ++k) {
+            int q = (int)((it[k].c[ax] - cmin[ax]) * scale);
+            q = q < 0 ? 0 : (q >= BINS ? BINS - 1 : q);
+            cnt[q] += it[k].n; ++items[q]; box_union(bb[q], it[k].b.box);
+        }
+        for (int q = 0; q < BINS - 1; ++q) {
+            Box l, r; int64_t nl = 0, nr = 0; int il = 0, ir = 0;
+            for (int i = 0; i < 3; ++i) { l.lo[i] = r.lo[i] = INFINITY; l.hi[i] = r.hi[i] = -INFINITY; }
+            for (int z = 0; z <= q; ++z) if (items[z]) { box_union(l, bb[z]); nl += cnt[z]; il += items[z]; }
+            for (int z = q + 1; z < BINS; ++z) if (items[z]) { box_union(r, bb[z]); nr += cnt[z]; ir += items[z]; }
+            if (!il || !ir) continue;
+            const float cost = half_area(l) * (float)nl + half_area(r) * (float)nr;
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = q; }
+        }
+    }
+    int mid;
+    if (best_axis >= 0) {
+        const float scale = BINS / (cmax[best_axis] - cmin[best_axis]), c0 = cmin[best_axis];
+        const int ax = best_axis, bbin = best_bin;
+        TopItem* m = std::partition(it.data() + lo, it.data() + hi, [=](const TopItem& x) {
+            int q = (int)((x.c[ax] - c0) * scale);
+            q = q < 0 ? 0 : (q >= BINS ? BINS - 1 : q);
+            return q <= bbin;
+        });
+        mid = (int)(m - it.data());
+    } else mid = (lo + hi) / 2;
+    if (mid <= lo || mid >= hi) mid = (lo + hi) / 2;
+    const int32_t idx = (int32_t)out->nodes.size();
+    out->nodes.emplace_back();
+    const Built L = build_top_sah(out, it, lo, mid);
+    const Built R = build_top_sah(out, it, mid, hi);
+    set_node(out->nodes[idx], L, R);
+    Built r; r.ref = r.ref_fine = idx; r.box = L.box; box_union(r.box, R.box);
+    r.depth = 1 + std::max(L.depth, R.depth);
+    return r;
+}
+
+// Expected work of a random ray through the tree (surface-area heuristic): every inner node weighs its box area,
+// every leaf its box area times its triangle count.  Used to choose between candidate trees.
+double tree_cost(const FlatScene& f) {
+    double cost = 0;
+    for (const Node64& n : f.nodes) {
+        const int32_t ref[2] = {n.lref_fine, n.rref_fine};
+        const float* bx[2] = {n.lbox, n.rbox};
+        for (int s = 0; s < 2; ++s) {
+            if (ref[s] == RT_NONE) continue;
+            Box b; memcpy(b.lo, bx[s], 12); memcpy(b.hi, bx[s] + 3, 12);
+            const double a = half_area(b);
+            if (ref[s] >= 0) cost += a * 1.0;
+            else cost += a * 1.2 * f.tris[~ref[s]].run_fine;
+        }
+    }
+    return cost;
+}
+
+}  // namespace
+
+bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& exact, FlatScene* out, std::string* err) {
+    out->nodes.clear(); out->tris.clear(); out->info.clear(); out->nrm.clear();
+    out->n_leaves = 0; out->max_depth = 0;
+    SahBuilder b;
+    b.meshes = meshes; b.out = out;
+    int64_t total = 0;
+    for (int mi = 0; mi < n_meshes; ++mi) { b.first_of.push_back((int32_t)total); total += meshes[mi].n_tris; }
+    if (total <= 0 || total != (int64_t)exact.tris.size()) { *err = "triangle count mismatch between the two trees"; return false; }
+    b.rank_of.assign((size_t)total, 0);
+    for (size_t k = 0; k < exact.tris.size(); ++k) b.rank_of[exact.info[k].id] = exact.tris[k].rank;
+    b.refs.resize((size_t)total);
+    for (int mi = 0; mi < n_meshes; ++mi)
+        for (int t = 0; t < meshes[mi].n_tris; ++t) {
+            const float* a = meshes[mi].pos + (size_t)t * 9; const float* bb = a + 3; const float* c = a + 6;
+            SahRef& r = b.refs[(size_t)b.first_of[mi] + t];
+            for (int i = 0; i < 3; ++i) {
+                r.b.lo[i] = fminf(a[i], fminf(bb[i], c[i]));
+                r.b.hi[i] = fmaxf(a[i], fmaxf(bb[i], c[i]));
+                r.c[i] = 0.5f * r.b.lo[i] + 0.5f * r.b.hi[i];
+            }
+            r.id = b.first_of[mi] + t;
+        }
+    if (total <= SahBuilder::LEAF) {
+        out->nodes.emplace_back();
+        const Built leaf = b.build(0, (int)total, 0);
+        Node64 entry; memset(&entry, 0, sizeof(entry));
+        memcpy(entry.lbox, leaf.box.lo, 12); memcpy(entry.lbox + 3, leaf.box.hi, 12);
+        entry.lref = entry.lref_fine = leaf.ref; entry.rref = entry.rref_fine = RT_NONE;
+        out->nodes[0] = entry;
+        out->max_depth = 1;
+        return true;
+    }
+    // candidate 1: one tree over all triangles
+    const std::vector<SahRef> all = b.refs;
+    out->nodes.reserve((size_t)total); out->tris.reserve((size_t)total); out->info.reserve((size_t)total); out->nrm.reserve((size_t)total * 9);
+    const Built root = b.build(0, (int)total, 0);      // the root is the first node emitted: index 0
+    out->max_depth = root.depth;
+    if (root.ref != 0) { *err = "internal: tree root is not node 0"; return false; }
+    int n_nonempty = 0;
+    for (int mi = 0; mi < n_meshes; ++mi) n_nonempty += meshes[mi].n_tris > 0;
+    if (n_nonempty < 2) return true;
+    // candidate 2: a tree per mesh under a top tree over the meshes (keeps a few huge triangles, such as the walls of
+    // a room, from widening the boxes of everything they are mixed with)
+    FlatScene two;
+    two.nodes.reserve((size_t)total); two.tris.reserve((size_t)total); two.info.reserve((size_t)total); two.nrm.reserve((size_t)total * 9);
+    two.nodes.emplace_back();                           // node 0 = entry, filled in last
+    b.refs = all; b.out = &two;
+    std::vector<TopItem> items;
+    for (int mi = 0; mi < n_meshes; ++mi) {
+        if (meshes[mi].n_tris <= 0) continue;
+        TopItem ti;
+        ti.b = b.build(b.first_of[mi], b.first_of[mi] + meshes[mi].n_tris, 0);
+        ti.n = meshes[mi].n_tris;
+        for (int i = 0; i < 3; ++i) ti.c[i] = 0.5f * ti.b.box.lo[i] + 0.5f * ti.b.box.hi[i];
+        items.push_back(ti);
+    }
+    const Built top = build_top_sah(&two, items, 0, (int)items.size());
+    two.nodes[0] = two.nodes[top.ref];                  // copy the top node into slot 0 (its own slot stays unused)
+    memset(&two.nodes[top.ref], 0, sizeof(Node64));
+    two.nodes[top.ref].lref = two.nodes[top.ref].rref = two.nodes[top.ref].lref_fine = two.nodes[top.ref].rref_fine = RT_NONE;
+    two.max_depth = top.depth;
+    const double c_one = tree_cost(*out), c_two = tree_cost(two);
+    if (getenv("RT_AMD_DEBUG_TREE")) fprintf(stderr, "rt_amd: expected cost, one tree %.4g, tree per mesh %.4g\n", c_one, c_two);
+    if (c_two < c_one) *out = std::move(two);
     return true;
 }
 

@@ -19,4 +19,10 @@ struct FlatScene {
 // Builds the per-mesh trees and the top tree; returns false and fills *err on bad input.
 bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, std::string* err);
 
+// Second tree over the same triangles for the pruning traversal: one binned surface-area-heuristic tree over ALL
+// meshes (the pruning traversal's answer does not depend on the tree: ties are decided by the ranks taken from
+// `exact`), leaves of at most four triangles.  Fills nodes (both reference pairs the same), tris (run == run_fine),
+// info, nrm in its own leaf order.
+bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& exact, FlatScene* out, std::string* err);
+
 }  // namespace rt

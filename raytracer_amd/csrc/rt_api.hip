@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -50,7 +51,8 @@ enum { RT_N_COUNTERS = 16 + rt::RT_TRACED_SLOTS * rt::RT_TRACED_STRIDE * 2 };   
 
 struct rt_scene {
     int device = 0;
-    rt::DScene d{};
+    rt::DScene d{};                          // the reference's trees (exact_boxes)
+    rt::DScene d_fast{};                     // the surface-area-heuristic tree of the pruning traversal
     int64_t n_tris = 0, n_inner = 0, n_leaves = 0, max_depth = 0;
     int n_lights = 0;
     bool any_spawning_material = false;
@@ -169,6 +171,14 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
     if (flat.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    // RT_AMD_FAST_TREE=refined keeps the pruning traversal on the reference's trees with refined leaves (for comparisons)
+    const char* ft = getenv("RT_AMD_FAST_TREE");
+    const bool use_sah = !(ft && strcmp(ft, "refined") == 0);
+    rt::FlatScene fast;
+    if (use_sah) {
+        if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
+        if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    }
 
     rt_scene* sc = new rt_scene();
     (void)hipGetDevice(&sc->device);
@@ -190,6 +200,15 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
         rt_scene_destroy(sc);
         return rc;
     }
+    sc->d_fast = sc->d;
+    if (use_sah && ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
+                    (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
+                    (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
+                    (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK)) {
+        rt_scene_destroy(sc);
+        return rc;
+    }
+    const rt::DScene fast_ptrs = sc->d_fast;
     sc->d.n_lights = n_lights;
     for (int i = 0; i < n_lights; ++i) {
         static_assert(sizeof(rt::Light) == sizeof(rt_light_desc), "light layouts must match");
@@ -198,6 +217,8 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     memcpy(sc->d.cam.pos, camera->pos, 12); memcpy(sc->d.cam.up, camera->up, 12);
     memcpy(sc->d.cam.w, camera->w, 12); memcpy(sc->d.cam.side, camera->side, 12);
     sc->d.cam.near_clip = camera->near_clip; sc->d.cam.far_clip = camera->far_clip;
+    sc->d_fast = sc->d;
+    sc->d_fast.nodes = fast_ptrs.nodes; sc->d_fast.tris = fast_ptrs.tris; sc->d_fast.info = fast_ptrs.info; sc->d_fast.nrm = fast_ptrs.nrm;
     sc->n_lights = n_lights;
     sc->n_tris = (int64_t)flat.tris.size();
     sc->n_inner = (int64_t)flat.nodes.size();
@@ -253,7 +274,7 @@ static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0
         d_cn = nodes_out ? (uint32_t*)(base + 11 * n) : nullptr;
         d_ct = tris_out ? (uint32_t*)(base + 12 * n) : nullptr;
     }
-    rt::launch_trace(any_hit != 0, exact != 0, sc->d, d_org, d_dir, t0, t1, n, d_t, d_tri, d_n, d_cn, d_ct, s);
+    rt::launch_trace(any_hit != 0, exact != 0, exact ? sc->d : sc->d_fast, d_org, d_dir, t0, t1, n, d_t, d_tri, d_n, d_cn, d_ct, s);
     HIP_TRY(hipGetLastError());
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, s));
@@ -333,6 +354,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
 
     // replay in two passes (a lane per sample, then a lane per pixel) where a pixel's samples are many and its ray
     // trees can be deep; one fused pass otherwise (it moves fewer bytes)
+    const rt::DScene& D = exact ? sc->d : sc->d_fast;
     const bool two_pass = sc->any_spawning_material && spp2 >= RT_TWO_PASS_MIN_SAMPLES;
     const bool out_dev = is_device_ptr(rgb_out);
     float* d_out = rgb_out;
@@ -366,9 +388,9 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
             rt::Level& L = sc->lv[lvl].L;
             HIP_TRY(hipMemsetAsync(sc->d_counters, 0, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), s));
             if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
-            rt::launch_extend(exact, sc->d, P, L, n, sc->d_counters, counting ? (unsigned long long*)(sc->d_counters + 4) : nullptr, s);
+            rt::launch_extend(exact, D, P, L, n, sc->d_counters, counting ? (unsigned long long*)(sc->d_counters + 4) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
-            rt::launch_shadow(exact, sc->d, P, L, n * nl, d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
+            rt::launch_shadow(exact, D, P, L, n * nl, d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[2], s));
             if (!sc->any_spawning_material && !timing) {
                 // no material of the scene can spawn rays and nobody asked for counts: the level count is known
@@ -400,7 +422,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
                 return fail(RT_ERR_UNSUPPORTED, "a level of the ray tree exceeds 2^31 light-ray items; render a smaller rectangle");
             rc = ensure_level(sc->lv[lvl], kids, nl, false, two_pass);
             if (rc != RT_OK) return rc;
-            rt::launch_spawn(sc->d, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);
+            rt::launch_spawn(D, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);
             n = kids;
         }
         max_levels = std::max(max_levels, lvl);
@@ -408,8 +430,8 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         for (int q = 0; q < lvl; ++q) ls.lv[q] = sc->lv[q].L;
         if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
         const int64_t n0 = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;
-        if (two_pass) rt::launch_shade_sum(sc->d, P, ls, n0, n_pix, d_out + (int64_t)by * rw * 3, s);
-        else rt::launch_replay(sc->d, P, ls, n_pix, d_out + (int64_t)by * rw * 3, s);
+        if (two_pass) rt::launch_shade_sum(D, P, ls, n0, n_pix, d_out + (int64_t)by * rw * 3, s);
+        else rt::launch_replay(D, P, ls, n_pix, d_out + (int64_t)by * rw * 3, s);
         if (timing) {
             HIP_TRY(hipEventRecord(sc->ev[1], s));
             HIP_TRY(hipEventSynchronize(sc->ev[1]));

@@ -254,7 +254,7 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
     const int depth = meta_depth(in.packed);
     const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
     if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
-    const V3 o = in.o, d = in.d;
+    const V3 d = in.d;
     const V3 n = f4v(res_hit(L, i));
     const uint32_t key = in.key;
     const float weight = in.weight;
