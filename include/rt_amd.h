@@ -146,6 +146,15 @@ int rt_scene_destroy(rt_scene* scene);
 /* Shape of the flattened tree: counts[0]=triangles, [1]=inner nodes, [2]=leaves, [3]=max depth. */
 int rt_scene_info(const rt_scene* scene, int64_t counts[4]);
 
+/* Host-only check of the two tree builders (needs no device): builds, from the same input as rt_scene_create, the
+ * flattened form of the reference's trees (BVHNode::BVHNode, src/geometry.cpp:61-153; which = 0) or the
+ * surface-area-heuristic tree the pruning traversal walks (which = 1), verifies it (every triangle in exactly one
+ * leaf, every child box contains its subtree's triangles, leaf sizes, child references in range, tie ranks a
+ * permutation, depth within the traversal stack) and reports
+ * out[0]=triangles, [1]=node records, [2]=leaves, [3]=max depth, [4]=largest leaf, [5]=triangles reached from the
+ * entry node, [6]=nodes reached, [7]=0.  Returns RT_ERR_INVALID with a message when a check fails. */
+int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t out[8]);
+
 /* Replaces bool get_hit(const AABBTree&, const Ray*, float t0, float t1, hitrec&)
  * (src/render_thread.h:17, src/render_thread.cpp:5-23) in batch form.
  * org/dir: [n][3] floats, host or device.  t_out[n] = hit distance or +inf; tri_out[n] = global

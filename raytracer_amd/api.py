@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
-EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_trace",
+EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
            "rt_trace_counted", "rt_render_rect", "rt_resolve_u8"]
 
 
@@ -41,6 +41,7 @@ def lib():
                                       C.POINTER(LightDesc), C.c_int, C.POINTER(CameraDesc), C.POINTER(vp)]
         L.rt_scene_destroy.argtypes = [vp]
         L.rt_scene_info.argtypes = [vp, C.POINTER(i64)]
+        L.rt_tree_check.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(i64)]
         L.rt_trace.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp]
         L.rt_trace_counted.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.rt_render_rect.argtypes = [vp, C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int, vp,
@@ -53,6 +54,16 @@ def lib():
 def _check(rc, what):
     if rc != 0:
         raise RtError("%s failed (%d): %s" % (what, rc, lib().rt_last_error().decode()))
+
+
+def tree_check(scene, which):
+    """Builds one of the two trees of a scene on the host (0: the reference's trees flattened, 1: the tree the pruning
+    traversal walks), verifies its invariants and returns its shape.  Needs no GPU."""
+    meshes, _, _, _, keep = pack_scene(scene)
+    c = (C.c_int64 * 8)()
+    _check(lib().rt_tree_check(meshes, len(scene.meshes), int(which), c), "rt_tree_check")
+    del keep
+    return dict(tris=c[0], nodes=c[1], leaves=c[2], depth=c[3], max_leaf=c[4], reached_tris=c[5], reached_nodes=c[6])
 
 
 def init(device=-1):

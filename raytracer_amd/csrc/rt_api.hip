@@ -232,6 +232,79 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     return RT_OK;
 }
 
+int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t out[8]) {
+    if (!meshes || n_meshes <= 0 || !out || (which != 0 && which != 1)) return fail(RT_ERR_INVALID, "rt_tree_check: bad argument");
+    rt::FlatScene flat, fast;
+    std::string err;
+    if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
+    if (which == 1 && !rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
+    const rt::FlatScene& f = which ? fast : flat;
+    const int64_t nt = (int64_t)f.tris.size(), nn = (int64_t)f.nodes.size();
+    if ((int64_t)f.info.size() != nt || (int64_t)f.nrm.size() != nt * 9) return fail(RT_ERR_INVALID, "tree check: array sizes differ");
+    // original vertices by global triangle id
+    std::vector<const float*> vert((size_t)nt);
+    { int64_t id = 0; for (int m = 0; m < n_meshes; ++m) for (int t = 0; t < meshes[m].n_tris; ++t) vert[(size_t)id++] = meshes[m].pos + (size_t)t * 9; }
+    std::vector<uint8_t> seen_tri((size_t)nt, 0), seen_rank((size_t)nt, 0), seen_node((size_t)nn, 0);
+    int64_t reached_tris = 0, reached_nodes = 0, leaves = 0, max_leaf = 0, max_depth = 0;
+    struct Item { int32_t ref; float box[6]; int depth; };
+    std::vector<Item> todo;
+    auto push_children = [&](int32_t node, int depth) -> bool {
+        if (node < 0 || node >= nn || seen_node[(size_t)node]) return false;
+        seen_node[(size_t)node] = 1; ++reached_nodes;
+        const rt::Node64& n = f.nodes[(size_t)node];
+        const int32_t refs[2] = {which ? n.lref_fine : n.lref, which ? n.rref_fine : n.rref};
+        for (int s = 0; s < 2; ++s) {
+            if (refs[s] == rt::RT_NONE) continue;
+            Item it; it.ref = refs[s]; it.depth = depth + 1;
+            memcpy(it.box, s ? n.rbox : n.lbox, 24);
+            todo.push_back(it);
+        }
+        return true;
+    };
+    if (!push_children(0, 0)) return fail(RT_ERR_INVALID, "tree check: no entry node");
+    while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        max_depth = std::max<int64_t>(max_depth, it.depth);
+        if (it.ref >= 0) {
+            // a child box must contain the boxes of the child's own children
+            if (it.ref >= nn) return fail(RT_ERR_INVALID, "tree check: node reference out of range");
+            const rt::Node64& c = f.nodes[(size_t)it.ref];
+            const int32_t r2[2] = {which ? c.lref_fine : c.lref, which ? c.rref_fine : c.rref};
+            for (int s = 0; s < 2; ++s) {
+                if (r2[s] == rt::RT_NONE) continue;
+                const float* b = s ? c.rbox : c.lbox;
+                for (int i = 0; i < 3; ++i)
+                    if (b[i] < it.box[i] || b[3 + i] > it.box[3 + i]) return fail(RT_ERR_INVALID, "tree check: a child box sticks out of its parent's");
+            }
+            if (!push_children(it.ref, it.depth)) return fail(RT_ERR_INVALID, "tree check: node reached twice or out of range");
+            continue;
+        }
+        const int64_t first = ~it.ref;
+        if (first < 0 || first >= nt) return fail(RT_ERR_INVALID, "tree check: leaf reference out of range");
+        const int64_t run = which ? f.tris[(size_t)first].run_fine : f.tris[(size_t)first].run;
+        if (run <= 0 || first + run > nt) return fail(RT_ERR_INVALID, "tree check: leaf run out of range");
+        ++leaves; max_leaf = std::max(max_leaf, run);
+        for (int64_t k = first; k < first + run; ++k) {
+            if (seen_tri[(size_t)k]) return fail(RT_ERR_INVALID, "tree check: triangle in two leaves");
+            seen_tri[(size_t)k] = 1; ++reached_tris;
+            const int64_t left = which ? f.tris[(size_t)k].run_fine : f.tris[(size_t)k].run;
+            if (left != first + run - k) return fail(RT_ERR_INVALID, "tree check: run lengths inside a leaf do not count down");
+            const int32_t id = f.info[(size_t)k].id, rank = f.tris[(size_t)k].rank;
+            if (id < 0 || id >= nt || rank < 0 || rank >= nt || seen_rank[(size_t)rank]) return fail(RT_ERR_INVALID, "tree check: ids or tie ranks are not a permutation");
+            seen_rank[(size_t)rank] = 1;
+            const float* v = vert[(size_t)id];
+            if (f.tris[(size_t)k].ax != v[0] || f.tris[(size_t)k].ay != v[1] || f.tris[(size_t)k].az != v[2]) return fail(RT_ERR_INVALID, "tree check: triangle does not match its id");
+            for (int c3 = 0; c3 < 3; ++c3)
+                for (int i = 0; i < 3; ++i)
+                    if (v[c3 * 3 + i] < it.box[i] || v[c3 * 3 + i] > it.box[3 + i]) return fail(RT_ERR_INVALID, "tree check: a vertex lies outside its leaf box");
+        }
+    }
+    if (reached_tris != nt) return fail(RT_ERR_INVALID, "tree check: not every triangle is reachable");
+    if (max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    out[0] = nt; out[1] = nn; out[2] = leaves; out[3] = max_depth; out[4] = max_leaf; out[5] = reached_tris; out[6] = reached_nodes; out[7] = 0;
+    return RT_OK;
+}
+
 int rt_scene_destroy(rt_scene* sc) {
     if (!sc) return RT_OK;
     for (void* p : sc->owned) (void)hipFree(p);
