@@ -22,6 +22,8 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -260,6 +262,7 @@ struct SahBuilder {
     const rt_mesh_desc* meshes;
     std::vector<int32_t> mesh_of, first_of;   // per mesh: first global id; per global id lookups go through these
     std::vector<int32_t> rank_of;             // by global triangle id
+    const int32_t* rank_ptr = nullptr;        // the same table when it is owned elsewhere
     FlatScene* out;
 
     void emit_tri(int32_t id, int run) {
@@ -269,7 +272,7 @@ struct SahBuilder {
         Tri48 q;
         q.ax = a[0]; q.ay = a[1]; q.az = a[2]; q.run = run;
         q.abx = a[0] - b[0]; q.aby = a[1] - b[1]; q.abz = a[2] - b[2]; q.run_fine = run;
-        q.acx = a[0] - c[0]; q.acy = a[1] - c[1]; q.acz = a[2] - c[2]; q.rank = rank_of[id];
+        q.acx = a[0] - c[0]; q.acy = a[1] - c[1]; q.acz = a[2] - c[2]; q.rank = rank_ptr ? rank_ptr[id] : rank_of[id];
         out->tris.push_back(q);
         TriInfo fi; fi.id = id; fi.mesh = mi;
         out->info.push_back(fi);
@@ -459,38 +462,78 @@ bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& 
         out->max_depth = 1;
         return true;
     }
-    // candidate 1: one tree over all triangles
-    const std::vector<SahRef> all = b.refs;
-    out->nodes.reserve((size_t)total); out->tris.reserve((size_t)total); out->info.reserve((size_t)total); out->nrm.reserve((size_t)total * 9);
-    const Built root = b.build(0, (int)total, 0);      // the root is the first node emitted: index 0
-    out->max_depth = root.depth;
-    if (root.ref != 0) { *err = "internal: tree root is not node 0"; return false; }
     int n_nonempty = 0;
     for (int mi = 0; mi < n_meshes; ++mi) n_nonempty += meshes[mi].n_tris > 0;
-    if (n_nonempty < 2) return true;
+    const std::vector<SahRef> all = b.refs;
+    // candidate 1: one tree over all triangles (not tried for scenes of very many meshes: instanced fields, where the
+    // per-mesh trees are the natural clusters and the build time matters)
+    const bool try_one = n_nonempty < 2 || n_nonempty <= 64;
+    if (try_one) {
+        out->nodes.reserve((size_t)total); out->tris.reserve((size_t)total); out->info.reserve((size_t)total); out->nrm.reserve((size_t)total * 9);
+        const Built root = b.build(0, (int)total, 0);      // the root is the first node emitted: index 0
+        out->max_depth = root.depth;
+        if (root.ref != 0) { *err = "internal: tree root is not node 0"; return false; }
+        if (n_nonempty < 2) return true;
+    }
     // candidate 2: a tree per mesh under a top tree over the meshes (keeps a few huge triangles, such as the walls of
-    // a room, from widening the boxes of everything they are mixed with)
+    // a room, from widening the boxes of everything they are mixed with).  The per-mesh builds are independent and run
+    // on a few host threads, each into a fragment of its own; the fragments are then spliced with shifted references.
+    struct Frag { FlatScene f; Built root; };
+    std::vector<Frag> frags((size_t)n_meshes);
+    {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int mi = next.fetch_add(1);
+                if (mi >= n_meshes) break;
+                const int n = meshes[mi].n_tris;
+                if (n <= 0) continue;
+                SahBuilder w;
+                w.meshes = meshes; w.first_of = b.first_of; w.out = &frags[(size_t)mi].f;
+                w.rank_of.clear();
+                w.rank_ptr = b.rank_of.data();
+                w.refs.assign(all.begin() + b.first_of[mi], all.begin() + b.first_of[mi] + n);
+                frags[(size_t)mi].root = w.build(0, n, 0);
+            }
+        };
+        const int n_threads = (int)std::max(1u, std::min(16u, std::min((unsigned)n_nonempty, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
     FlatScene two;
     two.nodes.reserve((size_t)total); two.tris.reserve((size_t)total); two.info.reserve((size_t)total); two.nrm.reserve((size_t)total * 9);
     two.nodes.emplace_back();                           // node 0 = entry, filled in last
-    b.refs = all; b.out = &two;
     std::vector<TopItem> items;
     for (int mi = 0; mi < n_meshes; ++mi) {
         if (meshes[mi].n_tris <= 0) continue;
+        Frag& fr = frags[(size_t)mi];
+        const int32_t node_off = (int32_t)two.nodes.size(), tri_off = (int32_t)two.tris.size();
+        auto shift = [&](int32_t ref) { return ref == RT_NONE ? ref : (ref >= 0 ? ref + node_off : ~(~ref + tri_off)); };
+        for (Node64 n : fr.f.nodes) {
+            n.lref = shift(n.lref); n.rref = shift(n.rref); n.lref_fine = shift(n.lref_fine); n.rref_fine = shift(n.rref_fine);
+            two.nodes.push_back(n);
+        }
+        two.tris.insert(two.tris.end(), fr.f.tris.begin(), fr.f.tris.end());
+        two.info.insert(two.info.end(), fr.f.info.begin(), fr.f.info.end());
+        two.nrm.insert(two.nrm.end(), fr.f.nrm.begin(), fr.f.nrm.end());
+        two.n_leaves += fr.f.n_leaves;
         TopItem ti;
-        ti.b = b.build(b.first_of[mi], b.first_of[mi] + meshes[mi].n_tris, 0);
+        ti.b = fr.root; ti.b.ref = ti.b.ref_fine = shift(fr.root.ref);
         ti.n = meshes[mi].n_tris;
         for (int i = 0; i < 3; ++i) ti.c[i] = 0.5f * ti.b.box.lo[i] + 0.5f * ti.b.box.hi[i];
         items.push_back(ti);
+        fr.f = FlatScene();                                  // release the fragment
     }
     const Built top = build_top_sah(&two, items, 0, (int)items.size());
     two.nodes[0] = two.nodes[top.ref];                  // copy the top node into slot 0 (its own slot stays unused)
     memset(&two.nodes[top.ref], 0, sizeof(Node64));
     two.nodes[top.ref].lref = two.nodes[top.ref].rref = two.nodes[top.ref].lref_fine = two.nodes[top.ref].rref_fine = RT_NONE;
     two.max_depth = top.depth;
-    const double c_one = tree_cost(*out), c_two = tree_cost(two);
+    const double c_one = try_one ? tree_cost(*out) : 0.0, c_two = tree_cost(two);
     if (getenv("RT_AMD_DEBUG_TREE")) fprintf(stderr, "rt_amd: expected cost, one tree %.4g, tree per mesh %.4g\n", c_one, c_two);
-    if (c_two < c_one) *out = std::move(two);
+    if (!try_one || c_two < c_one) *out = std::move(two);
     return true;
 }
 
