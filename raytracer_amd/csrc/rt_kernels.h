@@ -67,6 +67,8 @@ struct Level {
 RT_HD int32_t res_tri(const Level& L, int64_t i) { return L.implicit ? L.tri[i] : L.rec[i].tri; }
 RT_HD float4 res_pos(const Level& L, int64_t i) { return L.implicit ? L.pos[i] : *reinterpret_cast<const float4*>(&L.rec[i].px); }
 RT_HD float4 res_hit(const Level& L, int64_t i) { return L.implicit ? L.hit[i] : *reinterpret_cast<const float4*>(&L.rec[i].nx); }
+// children the nearest-hit search announced for node i
+RT_HD int res_kid_count(const Level& L, int64_t i) { return L.implicit ? L.kids[i].y : (int)((uint32_t)L.rec[i].flags >> 24); }
 RT_HD void set_kids(const Level& L, int64_t i, int32_t base, int cnt) {
     if (L.implicit) { int2 kd; kd.x = base; kd.y = cnt; L.kids[i] = kd; }
     else { L.rec[i].kid_base = base; reinterpret_cast<uint8_t*>(&L.rec[i].flags)[3] = (uint8_t)cnt; }
@@ -184,7 +186,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     }
     if (L.implicit) {
         L.tri[i] = hit ? h.tri : -1;
-        if (P.can_spawn) { int2 kd; kd.x = -1; kd.y = 0; L.kids[i] = kd; }
+        if (P.can_spawn) { int2 kd; kd.x = -1; kd.y = kids; L.kids[i] = kd; }
         if (hit) {
             L.hit[i] = hn; L.pos[i] = pk;
             if (kind == 3) L.aux[i] = r_theta;
@@ -195,7 +197,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
             *reinterpret_cast<float4*>(&R->px) = pk;
             *reinterpret_cast<float4*>(&R->nx) = hn;
         }
-        *reinterpret_cast<int4*>(&R->kid_base) = mk_i4(-1, flags, RT_F2I(in.weight), hit ? h.tri : -1);
+        *reinterpret_cast<int4*>(&R->kid_base) = mk_i4(-1, flags | (kids << 24), RT_F2I(in.weight), hit ? h.tri : -1);
         *reinterpret_cast<int4*>(&R->aux) = mk_i4(RT_F2I(r_theta), in.comp, 0, 0);
     }
     return kids;
@@ -247,7 +249,8 @@ RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, S
 }
 
 // ------------------------------------------------------------------------------------------------- spawn
-RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
+// writes the children of node i into N[base ...]; the caller reserved res_kid_count(L, i) places
+RT_HD void spawn_children(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t base, int64_t i) {
     const int tri = res_tri(L, i);
     if (tri < 0) return;
     const NodeIn in = node_in(sc, P, L, i);
@@ -264,7 +267,6 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
     const V3 rd = v3(d.x - pp * n.x, d.y - pp * n.y, d.z - pp * n.z);
     if (M.kind == 2) {                                              // src/render_thread.cpp:239-280
         const int cnt = P.spr + 1;
-        const uint32_t base = RT_ATOMIC_ADD(next_count, (uint32_t)cnt);
         for (int k = 0; k < cnt; ++k) {
             const V3 dk = (k < P.spr) ? split_dir(rd, P.ray_eps, P, key, SITE_REFLECT_SPLIT, 0, (uint32_t)k) : rd;
             const uint32_t ck = node_child(key, (uint32_t)k);
@@ -280,7 +282,6 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
         const float r_theta = refract_dir(d, n, refraci, M.refractivity, td);
         const bool both = !(r_theta <= 0);
         const int cnt = both ? 2 : 1;
-        const uint32_t base = RT_ATOMIC_ADD(next_count, (uint32_t)cnt);
         const int d_rf = (refraci == 1) ? P.D : depth - 1;
         const int d_rt = (refraci == 1) ? P.Dr : depth - 1;
         const int zi = RT_F2I(M.refractivity);
@@ -298,6 +299,12 @@ RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, c
         }
         set_kids(L, i, (int32_t)base, cnt);
     }
+}
+
+// one node at a time (the kernel reserves the places of a whole wave with one atomic instead)
+RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
+    const int cnt = (P.can_spawn && res_tri(L, i) >= 0) ? res_kid_count(L, i) : 0;
+    if (cnt > 0) spawn_children(sc, P, L, N, RT_ATOMIC_ADD(next_count, (uint32_t)cnt), i);
 }
 
 // ------------------------------------------------------------------------------------------------ replay
