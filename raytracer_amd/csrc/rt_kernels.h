@@ -31,7 +31,8 @@ struct alignas(64) NodeRec {
     int32_t kid_base;                 // first child in the next level (written by spawn)
     int32_t flags;                    // type | depth << 8 | rank << 16 | REC_SAME_MEDIUM; byte 3 = number of children
     float weight;                     // src/ray.h:36
-    int32_t tri;                      // triangle position (traversal order) or -1
+    int32_t tri;                      // -1: the ray hit nothing; otherwise the MATERIAL index of the hit mesh (all that the
+                                      // later stages want from the triangle, and three dependent loads nearer)
     float aux;                        // Schlick term r_theta of a refractive spawn
     int32_t comp;                     // node (this level) whose ray the companion shadow ray repeats
     uint8_t unocc[8];                 // per light: light rays that reached it, out of spr+1 (written by shadow, only
@@ -64,7 +65,10 @@ struct Level {
 };
 
 // ---- access to a node's results in either layout
+// >= 0 where node i's ray hit something (a triangle position at level 0, a material index below: see NodeRec)
 RT_HD int32_t res_tri(const Level& L, int64_t i) { return L.implicit ? L.tri[i] : L.rec[i].tri; }
+// material index of the hit; v = res_tri(L, i) >= 0
+RT_HD int32_t res_material(const DScene& sc, const Level& L, int32_t v) { return L.implicit ? sc.mesh_mat[sc.info[v].mesh] : v; }
 RT_HD float4 res_pos(const Level& L, int64_t i) { return L.implicit ? L.pos[i] : *reinterpret_cast<const float4*>(&L.rec[i].px); }
 RT_HD float4 res_hit(const Level& L, int64_t i) { return L.implicit ? L.hit[i] : *reinterpret_cast<const float4*>(&L.rec[i].nx); }
 // children the nearest-hit search announced for node i
@@ -168,12 +172,13 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     float r_theta = 0.f;
     int kids = 0, flags = in.packed;
     float4 pk = mk4(v3(0, 0, 0), 0.f), hn = mk4(v3(0, 0, 0), INFINITY);
-    int kind = 0;
+    int kind = 0, mat = -1;
     if (hit) {
         const V3 n = hit_normal(sc, h);
         pk = mk4(point_at(in.o, d, h.t), RT_I2F((int32_t)in.key));
         hn = mk4(n, h.t);
-        const Material& M = sc.mats[sc.mesh_mat[sc.info[h.tri].mesh]];
+        mat = sc.mesh_mat[sc.info[h.tri].mesh];
+        const Material& M = sc.mats[mat];
         kind = M.kind;
         if (RT_I2F(in.refraci) == M.refractivity) flags |= REC_SAME_MEDIUM;
         const int depth = meta_depth(in.packed);
@@ -197,7 +202,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
             *reinterpret_cast<float4*>(&R->px) = pk;
             *reinterpret_cast<float4*>(&R->nx) = hn;
         }
-        *reinterpret_cast<int4*>(&R->kid_base) = mk_i4(-1, flags | (kids << 24), RT_F2I(in.weight), hit ? h.tri : -1);
+        *reinterpret_cast<int4*>(&R->kid_base) = mk_i4(-1, flags | (kids << 24), RT_F2I(in.weight), mat);
         *reinterpret_cast<int4*>(&R->aux) = mk_i4(RT_F2I(r_theta), in.comp, 0, 0);
     }
     return kids;
@@ -255,7 +260,7 @@ RT_HD void spawn_children(const DScene& sc, const RenderParams& P, const Level& 
     if (tri < 0) return;
     const NodeIn in = node_in(sc, P, L, i);
     const int depth = meta_depth(in.packed);
-    const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
+    const Material& M = sc.mats[res_material(sc, L, tri)];
     if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
     const V3 d = in.d;
     const V3 n = f4v(res_hit(L, i));
@@ -351,6 +356,16 @@ struct RFrame {
     V3 c; float contrib, tpc; // colour state handed to the children (src/render_thread.cpp:245-248, :348, :367-382)
 };
 
+// A material in four 16-byte loads (the array is 64-byte aligned and a material is 64 bytes).
+RT_HD Material load_material(const Material* p) {
+    static_assert(sizeof(Material) == 64, "material layout");
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 v[4] = {q[0], q[1], q[2], q[3]};
+    Material m;
+    memcpy(&m, v, sizeof(m));
+    return m;
+}
+
 // One sample: walks the ray tree under level-0 node g in the reference's pop order (the newest pushed ray pops
 // first) and hands every drawn colour to emit(level, node, colour, weight).
 // The per-pixel shadow record (src/render_thread.cpp:134-171) is refreshed by the level-0 node before anything below
@@ -371,19 +386,26 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
         const Level& L = lv[lvl];
         // kid_base, flags (type, depth, children), weight, triangle; then the rest of what this node needs
         int4 head; float aux = 0.f; int comp_tri;
-        const uint8_t* un;
+        uint32_t un_lo = 0, un_hi = 0;               // per-light counts, one byte each
         if (L.implicit) {
             head.w = L.tri[i];
             head.y = meta_pack(RAY_REFLECT, P.D, 0); head.z = RT_F2I(1.f); head.x = -1;
             if (P.can_spawn && head.w >= 0) { const int2 kd = L.kids[i]; head.x = kd.x; head.y |= kd.y << 24; }
             comp_tri = head.w;                       // the companion repeats the node's own ray
-            un = L.unocc + i * sc.n_lights;
+            if (comp_tri >= 0)
+                for (int li = 0; li < sc.n_lights; ++li) {
+                    const uint32_t u = L.unocc[i * sc.n_lights + li];
+                    if (li < 4) un_lo |= u << (8 * li); else un_hi |= u << (8 * (li - 4));
+                }
         } else {
+            // the whole record in a few 16-byte loads: lanes are at unrelated records, and the memory pipeline pays
+            // per instruction and lane, not per byte
             const NodeRec* R = L.rec + i;
             head = *reinterpret_cast<const int4*>(&R->kid_base);
-            aux = R->aux;
-            comp_tri = L.rec[R->comp].tri;
-            un = R->unocc;
+            const int4 tail = *reinterpret_cast<const int4*>(&R->aux);
+            aux = RT_I2F(tail.x);
+            comp_tri = L.rec[tail.y].tri;
+            un_lo = (uint32_t)tail.z; un_hi = (uint32_t)tail.w;
         }
         const int type = meta_type(head.y), depth = meta_depth(head.y), n_kids = (int)((uint32_t)head.y >> 24);
         const float weight = RT_I2F(head.z);
@@ -391,14 +413,14 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
         // its companion shadow-type ray pops just before it (:134-171)
         if (comp_tri >= 0)
             for (int li = 0; li < sc.n_lights; ++li) {
-                float sh_frac = (float)un[li];                                // +1 per light ray that hit nothing
+                float sh_frac = (float)(((li < 4 ? un_lo >> (8 * li) : un_hi >> (8 * (li - 4)))) & 255u);   // +1 per light ray that hit nothing
                 sh_frac /= (float)(P.spr + 1);
                 shadow_rec[li] = sh_frac;
             }
         bool draw = false, has_kids = false;
         V3 c = v3(0, 0, 0);
         if (tri >= 0) {
-            const Material& M = sc.mats[sc.mesh_mat[sc.info[tri].mesh]];
+            const Material M = load_material(sc.mats + res_material(sc, L, tri));
             const float4 hn = res_hit(L, i);
             const V3 n = f4v(hn);
             V3 p; uint32_t key;
