@@ -128,3 +128,32 @@ def test_tree_builders_on_degenerate_input(which):
         assert info["reached_tris"] == len(tris)
     two = Scene(meshes=[_soup(cases[0], "a"), _soup(cases[1], "b")], materials=base.materials[:1], lights=base.lights, camera=base.camera)
     assert api.tree_check(two, which)["reached_tris"] == 10
+
+
+def test_frame_driver_host_parts(tmp_path):
+    """Display-block order, report lines and the PNG writer of the headless frame driver (no GPU involved)."""
+    import struct
+    import zlib
+    from raytracer_amd import render
+    blocks = list(render.display_blocks(250, 130, 100))
+    assert blocks[0] == (0, 0, 100, 100) and blocks[2] == (200, 0, 250, 100) and blocks[-1] == (200, 100, 250, 130)
+    cover = np.zeros((130, 250), int)
+    for x0, y0, x1, y1 in blocks:
+        cover[y0:y1, x0:x1] += 1
+    assert (cover == 1).all()
+    opt, extras = parse_options("-spp 2\n-spr 3\n-bounce 3\n-dispw 64\n-disph 36\n-mpbs 50\n")
+    lines = render.report_lines(opt)
+    assert "Samples per pixel: 4" in lines and "Samples per ray: 4" in lines and "Resolution: 64 X 36" in lines
+    assert extras["mpbs"] == 50
+    img = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
+    p = str(tmp_path / "a.png")
+    render.write_png(p, img)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", raw[16:24]) == (7, 5)
+    idat = raw[raw.index(b"IDAT") + 4: raw.index(b"IEND") - 8]
+    rows = zlib.decompress(idat)
+    back = np.frombuffer(rows, np.uint8).reshape(5, 1 + 7 * 3)[:, 1:].reshape(5, 7, 3)
+    assert (back == img).all()
+    render.write_ppm(str(tmp_path / "a.ppm"), img)
+    assert open(str(tmp_path / "a.ppm"), "rb").read().endswith(img.tobytes())
+    assert render.find_scene(GOLDEN).endswith(".rtscene")

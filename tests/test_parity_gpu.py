@@ -259,3 +259,28 @@ def test_full_size_frame_properties(oracle_mod, bunny_scene):
     api.resolve_u8(out, out=u8d)
     torch.cuda.synchronize()
     assert (u8d.cpu().numpy() == u8).all()
+
+
+def test_headless_frame_driver(oracle_mod, tmp_path):
+    """`python -m raytracer_amd.render` end to end: option file in, image out, the bytes are the oracle's bytes; block by
+    block rendering gives the same image."""
+    import zlib
+    from raytracer_amd import render
+    scene_path = "%s/stanford_bunny.rtscene" % GOLDEN
+    optfile = tmp_path / "options.txt"
+    optfile.write_text("-dispw 96\n-disph 54\n-hfov 60\n-spp 2\n-spr 3\n-bounce 3\n-eps 0.0001\n-reps 0.1\n-mpbs 40\n")
+    out1, out2 = str(tmp_path / "a.png"), str(tmp_path / "b.ppm")
+    assert render.main([scene_path, str(optfile), "-o", out1, "--seed", "7", "--exact", "--log", str(tmp_path / "logs.txt")]) == 0
+    assert render.main([scene_path, str(optfile), "-o", out2, "--seed", "7", "--exact", "--blocks"]) == 0
+    sc = Scene.load(scene_path)
+    opt = Options(width=96, height=54, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-4, ray_eps=0.1,
+                  jitter_mode=RT_JITTER_HASH, seed=7, exact_boxes=1)
+    a, _ = oracle_mod.OracleScene(sc).render_rect(opt, 0, 0, 96, 54)
+    want = oracle_mod.resolve_u8(a)
+    raw = open(out1, "rb").read()
+    rows = zlib.decompress(raw[raw.index(b"IDAT") + 4: raw.index(b"IEND") - 8])
+    png = np.frombuffer(rows, np.uint8).reshape(54, 1 + 96 * 3)[:, 1:].reshape(54, 96, 3)
+    assert (png == want).all()
+    ppm = np.frombuffer(open(out2, "rb").read()[-54 * 96 * 3:], np.uint8).reshape(54, 96, 3)
+    assert (ppm == want).all()
+    assert "Samples per pixel: 4" in open(str(tmp_path / "logs.txt")).read()
