@@ -504,6 +504,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
         const int64_t n0 = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;
         if (two_pass) rt::launch_shade_sum(D, P, ls, n0, n_pix, d_out + (int64_t)by * rw * 3, s);
+        else if (!sc->any_spawning_material && spp2 <= 64) rt::launch_replay_flat(D, P, ls, n0 / spp2, d_out + (int64_t)by * rw * 3, s);
         else rt::launch_replay(D, P, ls, n_pix, d_out + (int64_t)by * rw * 3, s);
         if (timing) {
             HIP_TRY(hipEventRecord(sc->ev[1], s));

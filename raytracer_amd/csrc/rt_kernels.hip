@@ -90,6 +90,41 @@ __global__ __launch_bounds__(BLOCK) void k_replay(DScene sc, RenderParams P, Lev
     if (pl < n_pixels) body_replay(sc, P, ls.lv, pl, rgb_out);
 }
 
+// Replay of a frame that has only level 0 (no material spawns rays), one lane per SAMPLE: the samples of a pixel sit in
+// consecutive lanes (64 / spp^2 pixels per wave), every load is coalesced in node order, and the pixel's lanes then add
+// their colours in the reference's pop order (last sample first) through lane shuffles - the same additions in the
+// same order as the lane-per-pixel loop, with spp^2 times the lanes.
+struct EmitOne {
+    V3 c; float w; int drew;
+    __device__ __forceinline__ void operator()(int, int64_t, V3 col, float weight) { c = col; w = weight; drew = 1; }
+};
+
+__global__ __launch_bounds__(BLOCK) void k_replay_flat(DScene sc, RenderParams P, LevelSet ls, int64_t n_slots, float* rgb_out) {
+    const int spp2 = P.spp * P.spp, per_wave = 64 / spp2;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int sub = (int)fdiv((uint32_t)lane, P.div_spp2), smp = lane - sub * spp2;
+    const int64_t slot = wave * per_wave + sub;
+    const bool active = sub < per_wave && slot < n_slots;
+    EmitOne e; e.c = v3(0, 0, 0); e.w = 0.f; e.drew = 0;
+    if (active) replay_sample(sc, P, ls.lv, slot * spp2 + smp, e);
+    V3 sum = v3(0, 0, 0), wsum = v3(0, 0, 0);
+    for (int k = spp2 - 1; k >= 0; --k) {
+        const int src = lane - smp + k;
+        const float cx = __shfl(e.c.x, src, 64), cy = __shfl(e.c.y, src, 64), cz = __shfl(e.c.z, src, 64), w = __shfl(e.w, src, 64);
+        if (__shfl(e.drew, src, 64)) { sum = vadd(sum, v3(cx, cy, cz)); wsum = vadd(wsum, v3(w, w, w)); }
+    }
+    if (!active || smp != 0) return;
+    const uint32_t tile = (uint32_t)(slot >> 4), tile_y = fdiv(tile, P.div_tiles_x), tile_x = tile - tile_y * (uint32_t)((P.rw + 3) >> 2);
+    const int q = (int)(slot & 15);
+    const int px = (int)tile_x * 4 + ((q & 1) | ((q >> 1) & 2)), py = (int)tile_y * 4 + (((q >> 1) & 1) | ((q >> 2) & 2));
+    if (px >= P.rw || py >= P.band_rows) return;
+    const int64_t pl = (int64_t)py * P.rw + px;
+    rgb_out[pl * 3 + 0] = sum.x / wsum.x;
+    rgb_out[pl * 3 + 1] = sum.y / wsum.y;
+    rgb_out[pl * 3 + 2] = sum.z / wsum.z;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, RenderParams P, LevelSet ls, int64_t n) {
     const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (g < n) body_shade(sc, P, ls.lv, g);
@@ -147,6 +182,11 @@ void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const
 }
 void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_pixels, float* rgb_out, hipStream_t s) {
     if (n_pixels > 0) k_replay<<<blocks(n_pixels), BLOCK, 0, s>>>(sc, P, ls, n_pixels, rgb_out);
+}
+void launch_replay_flat(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_slots, float* rgb_out, hipStream_t s) {
+    if (n_slots <= 0) return;
+    const int64_t per_wave = 64 / (P.spp * P.spp);
+    k_replay_flat<<<blocks((n_slots + per_wave - 1) / per_wave * 64), BLOCK, 0, s>>>(sc, P, ls, n_slots, rgb_out);
 }
 void launch_shade_sum(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_nodes0, int64_t n_pixels, float* rgb_out, hipStream_t s) {
     if (n_nodes0 > 0) k_shade<<<blocks(n_nodes0), BLOCK, 0, s>>>(sc, P, ls, n_nodes0);

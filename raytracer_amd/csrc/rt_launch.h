@@ -17,6 +17,8 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
                    unsigned long long* work, hipStream_t s);
 void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s);
 void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_pixels, float* rgb_out, hipStream_t s);
+// replay of a frame with a single level, one lane per sample (spp^2 <= 64); n_slots = pixel slots incl. tile padding
+void launch_replay_flat(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_slots, float* rgb_out, hipStream_t s);
 // the replay in two passes: one lane per level-0 node shades its sample's tree into draw records, then one lane per
 // pixel adds them in pop order (levels must carry draw arrays, level 0 also `first`)
 void launch_shade_sum(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_nodes0, int64_t n_pixels, float* rgb_out, hipStream_t s);
