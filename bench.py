@@ -33,6 +33,10 @@ WORKLOADS = {
     # -spp 2 (4 samples per pixel), -spr 3, 3 bounces, 1920x1080 (reference README.md:26-40)
     "bunny_lambert_1080p": (lambda: scenes.bunny(), dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3,
                                                           eps=1e-4, ray_eps=0.1)),
+    # the same with a second directional light, as BASELINE.json words configs[0] (the shipped scene file has one light;
+    # the second one is this build's: direction (0.6, 0.7, -0.2) normalised, colour 0.6)
+    "bunny_lambert_2lights_1080p": (lambda: scenes.bunny(second_light=True),
+                                    dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-4, ray_eps=0.1)),
     # configs[1]: ground and dome Phong-reflective, 2 bounces (README.md:42-56)
     "bunny_phong_1080p": (lambda: scenes.bunny(phong_surroundings=True),
                           dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, ray_eps=0.1)),

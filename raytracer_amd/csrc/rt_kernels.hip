@@ -1,4 +1,6 @@
 // __global__ wrappers and launchers of the wavefront pipeline (bodies: rt_kernels.h).
+#include <algorithm>
+
 #include "rt_launch.h"
 
 namespace rt {
@@ -43,17 +45,21 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Lev
 // when its slowest ray is - a lane that looped over the item's rays would wait for the slowest lane once per ray.
 // The item's count is the population count of the wave's "reached the light" mask over the item's lanes.
 template <bool EXACT, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, unsigned long long* traced, unsigned long long* work) {
+__global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, FastDiv div_nodes, uint32_t n_nodes, unsigned long long* traced, unsigned long long* work) {
     const int R = P.spr + 1, per_wave = 64 / R;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int sub = (int)fdiv((uint32_t)lane, P.div_rays), k = lane - sub * R;
-    const int64_t w = wave * per_wave + sub;
+    // items are taken light by light (all nodes toward light 0, then light 1, ...): the rays of a wave then go toward
+    // the same light and share a direction octant; item number w = node * n_lights + light is what the records use
+    const int64_t v = wave * per_wave + sub;
+    const uint32_t light = fdiv((uint32_t)v, div_nodes);
+    const int64_t w = (int64_t)((uint32_t)v - light * n_nodes) * sc.n_lights + light;
     uint32_t did = 0, nn = 0, nt = 0;
     bool reached = false;
     RT_DECLARE_STACK(st);
     ShadowItem it;
-    if (sub < per_wave && w < n_items && shadow_item(sc, P, L, w, it)) {
+    if (sub < per_wave && v < n_items && shadow_item(sc, P, L, w, it)) {
         did = 1;
         reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     }
@@ -169,12 +175,14 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
     if (n_items <= 0) return;
     const int64_t per_wave = 64 / (P.spr + 1);
     const unsigned g = blocks((n_items + per_wave - 1) / per_wave * 64);
+    const uint32_t n_nodes = (uint32_t)(n_items / std::max(sc.n_lights, 1));
+    const FastDiv dn = make_fastdiv(n_nodes);
     if (work) {
-        if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, work);
-        else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, work);
+        if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);
+        else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);
     } else {
-        if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, nullptr);
-        else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, traced, nullptr);
+        if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
+        else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
     }
 }
 void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s) {
