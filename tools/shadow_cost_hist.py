@@ -39,3 +39,22 @@ for m in range(len(sc.meshes)):
                 sc.meshes[m].name, "occluded" if oc else "lit", sel.sum(), cn[sel].mean(), np.percentile(cn[sel], 50),
                 np.percentile(cn[sel], 90), cn[sel].max(), ct[sel].mean()))
 print("all: nodes mean %.1f, share of node fetches by rays above 2x the mean: %.2f" % (cn.mean(), cn[cn > 2 * cn.mean()].sum() / cn.sum()))
+
+# ---- what would sorting the cheap rays out buy?  Waves of 64 rays from 8x8 pixel blocks (all pixels, misses idle).
+full = np.zeros(W * H, np.int64)
+full[np.nonzero(hit)[0]] = cn
+img = full.reshape(H, W)[: H // 8 * 8, : W // 8 * 8]
+blocks = img.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+now = blocks.max(axis=1).sum()
+print("wave steps now (max per wave): %d, lane steps %d, utilisation %.3f" % (now, blocks.sum(), blocks.sum() / (64.0 * now)))
+for K in (3, 4, 6, 8):
+    first = np.minimum(blocks, K).max(axis=1).sum()                       # everybody does at most K steps
+    rest = blocks[blocks > K]                                             # the others start again, packed densely
+    pad = (-len(rest)) % 64
+    packed = np.concatenate([rest, np.zeros(pad, np.int64)]).reshape(-1, 64)
+    second = packed.max(axis=1).sum()
+    print("two passes, cut at %d steps: %d + %d = %d wave steps (%.2f of now); %.0f %% of the rays go to the second pass" % (
+        K, first, second, first + second, (first + second) / now, 100.0 * len(rest) / max((blocks > 0).sum(), 1)))
+srt = np.sort(blocks[blocks > 0])
+pad = (-len(srt)) % 64
+print("lower bound, rays sorted by cost: %.2f of now" % (np.concatenate([srt, np.zeros(pad, np.int64)]).reshape(-1, 64).max(axis=1).sum() / now))
