@@ -337,3 +337,25 @@ def test_ten_million_triangle_field_sample(oracle_mod):
     assert (np.isnan(a) == np.isnan(b)).all()
     fin = np.isfinite(a)
     assert np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,bit_exact", [("bunny_phong_1080p", True), ("mirror_room", True), ("glass_balls", False)])
+def test_full_size_strips_of_the_other_workloads(oracle_mod, name, bit_exact):
+    """Configurations two to four at their full size: two strips of each frame (where the oracle is affordable) against
+    the oracle, with the reference's box arithmetic; bit for bit except through expf on the refractive scene."""
+    import bench
+    make, kw = bench.WORKLOADS[name]
+    sc = make()
+    g, o = _pair(sc, oracle_mod)
+    opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=1, **kw)
+    W, H = opt.width, opt.height
+    for (x0, y0) in ((W // 2 - 20, H // 2), (W // 3, H // 4)):
+        a, sa = o.render_rect(opt, x0, y0, x0 + 40, y0 + 2)
+        b, sb = g.render_rect(opt, x0, y0, x0 + 40, y0 + 2)
+        assert (np.isnan(a) == np.isnan(b)).all()
+        if bit_exact:
+            assert bits_equal(a, b).all()
+        else:
+            fin = np.isfinite(a)
+            assert np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6)
+        assert sb.rays_any == sa.rays_any and 2 * sb.rays_closest == sa.rays_closest
