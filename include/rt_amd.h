@@ -16,6 +16,17 @@
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).
  * All work of a call is enqueued on that stream; calls that write to host
  * memory synchronise the stream before returning.
+ *
+ * Devices: a scene lives on the device that was current when it was created
+ * (one handle per GPU; rt_init(device) selects it).  Every call on a scene
+ * makes that device current for its duration and restores the caller's
+ * device, so one host thread can drive scenes on several GPUs in turn; the
+ * stream passed with a scene must belong to the scene's device.
+ *
+ * Ordering: calls on one scene handle are serialised on the host by a mutex
+ * and on the device by an event - a call's stream first waits for the work
+ * of the previous call on that handle, whichever stream that ran on.  Calls
+ * on different handles are independent.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -178,6 +189,17 @@ int rt_trace_counted(rt_scene* scene, const float* org, const float* dir, float 
  * rgb_out[(y - y0) * (x1 - x0) + (x - x0)][3], host or device.  stats may be NULL. */
 int rt_render_rect(rt_scene* scene, const rt_options* opt, int x0, int y0, int x1, int y1,
                    float* rgb_out, rt_stats* stats, void* stream);
+
+/* rt_render_rect for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit, with
+ * these limits: the scene has no reflective or refractive material (their ray queues grow with the frame), rgb_out is
+ * device memory, and one 4-row band of the rectangle fits the fixed workspace: ceil(width/4) * 16 * spp^2 samples at
+ * (36 + lights) bytes each within 64 MiB; larger ones are refused with RT_ERR_UNSUPPORTED.  Taller rectangles are
+ * rendered band by band.  The call makes no hipMalloc/hipFree: its queues live in one 64 MiB array that every GPU the
+ * library runs on holds until the process ends.  All calls on one GPU share that array, whatever their scene handle:
+ * calls that overlap on one GPU (different streams, or threads, without synchronisation between them) race. */
+int rt_render_rect_noalloc(rt_scene* scene, const rt_options* opt, int x0, int y0, int x1, int y1,
+                           float* rgb_out, rt_stats* stats, void* stream);
 
 /* Replaces the 8-bit conversion of save_jpg (src/main.cpp:157-167):
  * out[(H-1-y)*W + x][c] = max(0, min(255, (int)floor(rgb * 256.0))), NaN -> 0.  rgb is [H][W][3] with row 0

@@ -416,7 +416,10 @@ void render_pixel(const orc_scene& sc, const rt_options& o, int i, int j, float 
                     sh_frac /= n_rays;
                     shadow_rec[li] = sh_frac;
                 }
-            } else {                                                                // :177-410
+            } else if (rec.mesh >= 0) {                                             // :177-410
+                // rec.mesh < 0: a mesh reported a hit whose t is NaN (0/0 on a zero-area triangle), which get_hit
+                // never copies (:15); the reference then compares an unset mesh name with every mesh (:178-180),
+                // matches none and draws nothing
                 const MeshO& mesh = *sc.meshes[rec.mesh];
                 const rt_material_desc& M = sc.mats[mesh.material];
                 const bool use_refl = (M.kind == RT_MAT_PHONG || M.kind == RT_MAT_REFRAC);

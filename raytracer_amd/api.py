@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
 EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
-           "rt_trace_counted", "rt_render_rect", "rt_resolve_u8"]
+           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_resolve_u8"]
 
 
 class RtError(RuntimeError):
@@ -46,6 +46,7 @@ def lib():
         L.rt_trace_counted.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.rt_render_rect.argtypes = [vp, C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int, vp,
                                      C.POINTER(Stats), vp]
+        L.rt_render_rect_noalloc.argtypes = L.rt_render_rect.argtypes
         L.rt_resolve_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         _LIB = L
     return _LIB
@@ -121,14 +122,16 @@ class TracerScene:
                               _ptr(t), _ptr(tri), _ptr(nrm), stream), "rt_trace")
         return t, tri, nrm
 
-    def render_rect(self, opt, x0, y0, x1, y1, out=None, stats=True, stream=None):
+    def render_rect(self, opt, x0, y0, x1, y1, out=None, stats=True, stream=None, noalloc=False):
         """Renders the pixel rectangle; `out` may be a numpy array or a CUDA torch tensor [y1-y0, x1-x0, 3] float32
-        (device tensors are written in place, asynchronously on `stream`)."""
+        (device tensors are written in place, asynchronously on `stream`).  noalloc: through rt_render_rect_noalloc
+        (fixed workspace, device output only)."""
         if out is None:
             out = np.empty((y1 - y0, x1 - x0, 3), np.float32)
         st = Stats() if stats else None
-        _check(lib().rt_render_rect(self._h, C.byref(opt), x0, y0, x1, y1, _ptr(out),
-                                    C.byref(st) if st is not None else None, stream), "rt_render_rect")
+        fn = lib().rt_render_rect_noalloc if noalloc else lib().rt_render_rect
+        _check(fn(self._h, C.byref(opt), x0, y0, x1, y1, _ptr(out),
+                  C.byref(st) if st is not None else None, stream), fn.__name__)
         return out, st
 
 

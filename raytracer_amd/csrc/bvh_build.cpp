@@ -482,25 +482,31 @@ bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& 
     std::vector<Frag> frags((size_t)n_meshes);
     {
         std::atomic<int> next(0);
+        std::atomic<bool> failed(false);     // an exception must not leave a worker thread (it would end the process)
         auto work = [&]() {
-            for (;;) {
-                const int mi = next.fetch_add(1);
-                if (mi >= n_meshes) break;
-                const int n = meshes[mi].n_tris;
-                if (n <= 0) continue;
-                SahBuilder w;
-                w.meshes = meshes; w.first_of = b.first_of; w.out = &frags[(size_t)mi].f;
-                w.rank_of.clear();
-                w.rank_ptr = b.rank_of.data();
-                w.refs.assign(all.begin() + b.first_of[mi], all.begin() + b.first_of[mi] + n);
-                frags[(size_t)mi].root = w.build(0, n, 0);
-            }
+            try {
+                for (;;) {
+                    const int mi = next.fetch_add(1);
+                    if (mi >= n_meshes || failed.load()) break;
+                    const int n = meshes[mi].n_tris;
+                    if (n <= 0) continue;
+                    SahBuilder w;
+                    w.meshes = meshes; w.first_of = b.first_of; w.out = &frags[(size_t)mi].f;
+                    w.rank_of.clear();
+                    w.rank_ptr = b.rank_of.data();
+                    w.refs.assign(all.begin() + b.first_of[mi], all.begin() + b.first_of[mi] + n);
+                    frags[(size_t)mi].root = w.build(0, n, 0);
+                }
+            } catch (...) { failed.store(true); }
         };
-        const int n_threads = (int)std::max(1u, std::min(16u, std::min((unsigned)n_nonempty, std::thread::hardware_concurrency())));
+        int n_threads = (int)std::max(1u, std::min(16u, std::min((unsigned)n_nonempty, std::thread::hardware_concurrency())));
         std::vector<std::thread> pool;
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        try {
+            for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        } catch (...) { /* fewer threads than hoped for: the ones that started and this one share the work */ }
         work();
         for (auto& th : pool) th.join();
+        if (failed.load()) { *err = "out of host memory while building the trees"; return false; }
     }
     FlatScene two;
     two.nodes.reserve((size_t)total); two.tris.reserve((size_t)total); two.info.reserve((size_t)total); two.nrm.reserve((size_t)total * 9);

@@ -34,6 +34,29 @@ bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// Makes `dev` the current device for the scope and puts the caller's device back afterwards.
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// No exception may cross the C boundary: every extern "C" body with host allocations runs inside these.
+#define RT_API_BEGIN try {
+#define RT_API_END(fn_)                                                                            \
+    } catch (const std::bad_alloc&) { return fail(RT_ERR_INVALID, fn_ ": out of host memory");     \
+    } catch (const std::exception& e_) { return fail(RT_ERR_INVALID, std::string(fn_ ": ") + e_.what()); \
+    } catch (...) { return fail(RT_ERR_INVALID, fn_ ": unknown exception"); }
+
+enum { RT_MAX_DEVICES = 64 };
+
+// Staging buffers of rt_resolve_u8 for host images: one per device, grown on demand, kept until the process ends.
+struct Staging { void* p = nullptr; size_t cap = 0; std::mutex mu; };
+Staging g_staging[RT_MAX_DEVICES];
+
 struct LevelBuf {
     rt::Level L{};
     int64_t cap = 0;
@@ -65,8 +88,18 @@ struct rt_scene {
     uint32_t* h_counters = nullptr;          // pinned mirror
     float* d_stage = nullptr; int64_t stage_cap = 0;
     void* d_io = nullptr; int64_t io_cap = 0;  // staging for rt_trace / rt_resolve_u8 host buffers
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_fault = nullptr;             // set by a kernel whose traversal stack overflowed (cannot happen for a tree
+                                             // that passed the depth check; read back by every synchronising call)
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..3] per-kernel timing, [4..5] whole call
+    hipEvent_t ev_done = nullptr;            // end of the last call's work: the next call's stream waits for it before it
+    bool pending = false;                    // touches the workspace (calls may come on different streams)
 };
+
+// Fixed workspace of rt_render_rect_noalloc: one array per GPU, held from the library's load to the process's end.
+// In host code the NAME below is only a handle for hipGetSymbolAddress; the device address it returns is what kernels
+// and memsets get (scratch_address()).
+enum : size_t { RT_SCRATCH_BYTES = (size_t)64 << 20 };
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
 
 namespace {
 
@@ -135,6 +168,23 @@ int ensure_bytes(void** p, int64_t* cap, int64_t need) {
     return RT_OK;
 }
 
+// Device address of `scratch` on the CURRENT device (every GPU holds its own copy at its own address), looked up once
+// per device and kept.
+unsigned char* g_scratch_ptr[RT_MAX_DEVICES];
+std::mutex g_scratch_mu;
+int scratch_address(int dev, unsigned char** out) {
+    if (dev < 0 || dev >= RT_MAX_DEVICES) return fail(RT_ERR_UNSUPPORTED, "device index beyond RT_MAX_DEVICES");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned no address for the fixed workspace");
+        g_scratch_ptr[dev] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -154,13 +204,15 @@ int rt_init(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, cur));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-    return RT_OK;
+    unsigned char* sp = nullptr;                 // the fixed workspace of rt_render_rect_noalloc on this device
+    return scratch_address(cur, &sp);
 }
 
 int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_desc* materials, int n_materials,
                     const rt_light_desc* lights, int n_lights, const rt_camera_desc* camera, rt_scene** out) {
     if (!meshes || n_meshes <= 0 || !materials || n_materials <= 0 || !camera || !out || n_lights < 0 || (n_lights > 0 && !lights))
         return fail(RT_ERR_INVALID, "rt_scene_create: null or empty argument");
+    RT_API_BEGIN
     if (n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_UNSUPPORTED, "more lights than RT_MAX_LIGHTS");
     for (int i = 0; i < n_meshes; ++i) {
         if (meshes[i].material < 0 || meshes[i].material >= n_materials) return fail(RT_ERR_INVALID, "mesh material index out of range");
@@ -225,15 +277,21 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     sc->n_leaves = flat.n_leaves;
     sc->max_depth = flat.max_depth;
     hipError_t e = hipMalloc((void**)&sc->d_counters, RT_N_COUNTERS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, RT_N_COUNTERS * sizeof(uint32_t));
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&sc->ev[i]);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_fault, 256);
+    if (e == hipSuccess) e = hipMemset(sc->d_fault, 0, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, (RT_N_COUNTERS + 16) * sizeof(uint32_t));
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&sc->ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_done, hipEventDisableTiming);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, hipGetErrorString(e)); }
+    sc->d.fault = sc->d_fault; sc->d_fast.fault = sc->d_fault;
     *out = sc;
     return RT_OK;
+    RT_API_END("rt_scene_create")
 }
 
 int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t out[8]) {
     if (!meshes || n_meshes <= 0 || !out || (which != 0 && which != 1)) return fail(RT_ERR_INVALID, "rt_tree_check: bad argument");
+    RT_API_BEGIN
     rt::FlatScene flat, fast;
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
@@ -303,13 +361,18 @@ int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t o
     if (max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
     out[0] = nt; out[1] = nn; out[2] = leaves; out[3] = max_depth; out[4] = max_leaf; out[5] = reached_tris; out[6] = reached_nodes; out[7] = 0;
     return RT_OK;
+    RT_API_END("rt_tree_check")
 }
 
 int rt_scene_destroy(rt_scene* sc) {
     if (!sc) return RT_OK;
+    DeviceGuard dg(sc->device);
+    if (sc->pending && sc->ev_done) (void)hipEventSynchronize(sc->ev_done);    // work of the last call may still be running
     for (void* p : sc->owned) (void)hipFree(p);
     for (auto& b : sc->lv) free_level(b);
     if (sc->d_counters) (void)hipFree(sc->d_counters);
+    if (sc->d_fault) (void)hipFree(sc->d_fault);
+    if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->h_counters) (void)hipHostFree(sc->h_counters);
     if (sc->d_stage) (void)hipFree(sc->d_stage);
     if (sc->d_io) (void)hipFree(sc->d_io);
@@ -324,19 +387,43 @@ int rt_scene_info(const rt_scene* sc, int64_t counts[4]) {
     return RT_OK;
 }
 
+// Start and end of a call's use of the scene's workspace.  Calls on one handle may come on different streams: each
+// call's stream first waits for the end of the previous call's work, recorded in ev_done.
+static int workspace_begin(rt_scene* sc, hipStream_t s) {
+    if (sc->pending) HIP_TRY(hipStreamWaitEvent(s, sc->ev_done, 0));
+    return RT_OK;
+}
+static int workspace_end(rt_scene* sc, hipStream_t s) {
+    HIP_TRY(hipEventRecord(sc->ev_done, s));
+    sc->pending = true;
+    return RT_OK;
+}
+// The scene's fault word, fetched together with other results a call waits for anyway.
+static int check_fault(rt_scene* sc, hipStream_t s) {
+    uint32_t* h = sc->h_counters + RT_N_COUNTERS;
+    HIP_TRY(hipMemcpyAsync(h, sc->d_fault, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*h) return fail(RT_ERR_UNSUPPORTED, "a traversal stack overflowed: tree deeper than the traversal stack");
+    return RT_OK;
+}
+
 static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact,
                       float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* nodes_out, uint32_t* tris_out, void* stream) {
     if (!sc || n < 0 || (n > 0 && (!org || !dir || !t_out))) return fail(RT_ERR_INVALID, "rt_trace: null argument or negative count");
     if (n == 0) return RT_OK;
     hipStream_t s = (hipStream_t)stream;
+    DeviceGuard dg(sc->device);
+    if (!dg.ok) return fail(RT_ERR_HIP, "rt_trace: cannot make the scene's device current");
     std::lock_guard<std::mutex> lock(sc->mu);
     const bool dev = is_device_ptr(org);
     if (dev != is_device_ptr(dir) || dev != is_device_ptr(t_out)) return fail(RT_ERR_INVALID, "rt_trace: mix of host and device buffers");
     const float *d_org = org, *d_dir = dir;
     float *d_t = t_out, *d_n = nrm_out; int32_t* d_tri = tri_out; uint32_t *d_cn = nodes_out, *d_ct = tris_out;
+    int rc = workspace_begin(sc, s);
+    if (rc != RT_OK) return rc;
     if (!dev) {
         // layout of the staging block: org[3n] dir[3n] t[n] nrm[3n] tri[n] cn[n] ct[n]
-        int rc = ensure_bytes(&sc->d_io, &sc->io_cap, n * 13 * 4);
+        rc = ensure_bytes(&sc->d_io, &sc->io_cap, n * 13 * 4);
         if (rc != RT_OK) return rc;
         float* base = (float*)sc->d_io;
         HIP_TRY(hipMemcpyAsync(base, org, n * 12, hipMemcpyHostToDevice, s));
@@ -355,9 +442,9 @@ static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0
         if (tri_out) HIP_TRY(hipMemcpyAsync(tri_out, d_tri, n * 4, hipMemcpyDeviceToHost, s));
         if (nodes_out) HIP_TRY(hipMemcpyAsync(nodes_out, d_cn, n * 4, hipMemcpyDeviceToHost, s));
         if (tris_out) HIP_TRY(hipMemcpyAsync(tris_out, d_ct, n * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if ((rc = check_fault(sc, s)) != RT_OK) return rc;       // synchronises the stream
     }
-    return RT_OK;
+    return workspace_end(sc, s);
 }
 
 int rt_trace(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact_boxes,
@@ -370,7 +457,15 @@ int rt_trace_counted(rt_scene* sc, const float* org, const float* dir, float t0,
     return trace_impl(sc, org, dir, t0, t1, n, any_hit, exact_boxes, t_out, tri_out, nullptr, nodes_out, tris_out, stream);
 }
 
-int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
+// Where the first level's arrays and the counter block live when the caller may not allocate: carved out of one
+// fixed block (rt_render_rect_noalloc) instead of the scene's grow-on-demand buffers.
+struct FixedWorkspace { unsigned char* base; size_t bytes; };
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// rt_render_rect and rt_render_rect_noalloc (fixed != NULL).
+static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats,
+                       void* stream, const FixedWorkspace* fixed) {
     if (!sc || !o || !rgb_out) return fail(RT_ERR_INVALID, "rt_render_rect: null argument");
     if (o->width <= 0 || o->height <= 0 || x0 < 0 || y0 < 0 || x1 > o->width || x0 > x1 || y0 > y1)
         return fail(RT_ERR_INVALID, "rt_render_rect: rectangle outside the image");
@@ -412,10 +507,26 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     uint64_t work[4] = {0, 0, 0, 0};
     const int spp2 = o->spp * o->spp;
     const int nl = sc->n_lights;
+    const bool out_dev = is_device_ptr(rgb_out);
 
     // band height: a level-0 budget of samples; scenes that can spawn get a smaller one because levels multiply
     int64_t budget = (int64_t)1 << 24;
-    if (sc->any_spawning_material) {
+    uint32_t* d_counters = sc->d_counters;
+    const size_t counter_bytes = align_up(RT_N_COUNTERS * sizeof(uint32_t), 256);
+    const size_t slot_bytes = 16 + 16 + 4 + (size_t)std::max(nl, 1);           // hit, pos, tri, unocc per level-0 slot
+    if (fixed) {
+        if (sc->any_spawning_material)
+            return fail(RT_ERR_UNSUPPORTED, "rt_render_rect_noalloc: the scene has reflective or refractive materials, whose ray "
+                                            "queues grow with the frame; use rt_render_rect");
+        if (!out_dev) return fail(RT_ERR_INVALID, "rt_render_rect_noalloc: rgb_out must be device memory");
+        d_counters = (uint32_t*)fixed->base;
+        // four arrays, each rounded up to 256 bytes
+        budget = (int64_t)((fixed->bytes - counter_bytes - 4 * 256) / slot_bytes);
+        const int64_t min_band = (int64_t)((rw + 3) / 4) * 16 * spp2;           // one row of 4x4-pixel tiles
+        if (min_band > budget)
+            return fail(RT_ERR_UNSUPPORTED, "rt_render_rect_noalloc: rectangle too wide for the fixed workspace (" +
+                        std::to_string((long long)min_band) + " samples per 4-row band, limit " + std::to_string((long long)budget) + ")");
+    } else if (sc->any_spawning_material) {
         // levels below the first can hold many times the band's samples (a mirror hit spawns spr+1 rays per bounce);
         // a band must still be large enough to fill the GPU when there are many samples per pixel
         size_t free_b = 0, total_b = 0;
@@ -424,55 +535,69 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     }
     int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
     if (band_rows < rh) band_rows = std::max(4, band_rows & ~3);       // whole 4-row tiles per band
+    if (fixed)      // tile padding counts against the fixed block too
+        while (band_rows > 4 && (int64_t)((rw + 3) / 4) * ((band_rows + 3) / 4) * 16 * spp2 > budget) band_rows -= 4;
 
     // replay in two passes (a lane per sample, then a lane per pixel) where a pixel's samples are many and its ray
     // trees can be deep; one fused pass otherwise (it moves fewer bytes)
     const rt::DScene& D = exact ? sc->d : sc->d_fast;
     const bool two_pass = sc->any_spawning_material && spp2 >= RT_TWO_PASS_MIN_SAMPLES;
-    const bool out_dev = is_device_ptr(rgb_out);
+    int rc = workspace_begin(sc, s);
+    if (rc != RT_OK) return rc;
     float* d_out = rgb_out;
     if (!out_dev) {
-        int rc = ensure_bytes((void**)&sc->d_stage, &sc->stage_cap, (int64_t)rw * rh * 12);
+        rc = ensure_bytes((void**)&sc->d_stage, &sc->stage_cap, (int64_t)rw * rh * 12);
         if (rc != RT_OK) return rc;
         d_out = sc->d_stage;
     }
     const bool timing = stats != nullptr;
     float ms_extend = 0, ms_shadow = 0, ms_shade = 0, ms_total = 0;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    if (timing) {
-        HIP_TRY(hipEventCreate(&ev_begin)); HIP_TRY(hipEventCreate(&ev_end));
-        HIP_TRY(hipEventRecord(ev_begin, s));
-    }
+    if (timing) HIP_TRY(hipEventRecord(sc->ev[4], s));
     uint64_t rays_closest = 0, rays_any = 0;
     int max_levels = 0;
     // light rays traced: only counted when the caller asked for statistics (the count costs an atomic per wave)
-    unsigned long long* d_traced = timing ? (unsigned long long*)(sc->d_counters + 16) : nullptr;
+    unsigned long long* d_traced = timing ? (unsigned long long*)(d_counters + 16) : nullptr;
+    // a scene none of whose materials spawns rays has one level and its kernels never touch the counters unless
+    // statistics are asked for: such a frame is three launches and nothing else
+    const bool single_level_async = !sc->any_spawning_material && !timing;
 
     for (int by = 0; by < rh; by += band_rows) {
         const int rows = std::min(band_rows, rh - by);
         const int64_t n_pix = (int64_t)rows * rw;
         const int64_t n_real = n_pix * spp2;
         int64_t n = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;   // level-0 slots incl. tile padding
-        int rc = ensure_level(sc->lv[0], n, nl, true, two_pass);
-        if (rc != RT_OK) return rc;
+        rt::Level fixed_level{};
+        if (fixed) {
+            unsigned char* q = fixed->base + counter_bytes;
+            fixed_level.implicit = 1;
+            fixed_level.hit = (float4*)q; q += align_up((size_t)n * 16, 256);
+            fixed_level.pos = (float4*)q; q += align_up((size_t)n * 16, 256);
+            fixed_level.tri = (int32_t*)q; q += align_up((size_t)n * 4, 256);
+            fixed_level.unocc = (uint8_t*)q; q += align_up((size_t)n * std::max(nl, 1), 256);
+            if ((size_t)(q - fixed->base) > fixed->bytes) return fail(RT_ERR_UNSUPPORTED, "rt_render_rect_noalloc: band does not fit the fixed workspace");
+        } else {
+            rc = ensure_level(sc->lv[0], n, nl, true, two_pass);
+            if (rc != RT_OK) return rc;
+        }
         P.band_y0 = y0 + by; P.band_rows = rows;
         int lvl = 0;
+        rt::Level level0 = fixed ? fixed_level : sc->lv[0].L;
         for (;;) {
-            rt::Level& L = sc->lv[lvl].L;
-            HIP_TRY(hipMemsetAsync(sc->d_counters, 0, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), s));
+            rt::Level& L = (lvl == 0) ? level0 : sc->lv[lvl].L;
+            if (!single_level_async)
+                HIP_TRY(hipMemsetAsync(d_counters, 0, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), s));
             if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
-            rt::launch_extend(exact, D, P, L, n, sc->d_counters, counting ? (unsigned long long*)(sc->d_counters + 4) : nullptr, s);
+            rt::launch_extend(exact, D, P, L, n, d_counters, counting ? (unsigned long long*)(d_counters + 4) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
-            rt::launch_shadow(exact, D, P, L, n * nl, d_traced, counting ? (unsigned long long*)(sc->d_counters + 8) : nullptr, s);
+            rt::launch_shadow(exact, D, P, L, n * nl, d_traced, counting ? (unsigned long long*)(d_counters + 8) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[2], s));
-            if (!sc->any_spawning_material && !timing) {
-                // no material of the scene can spawn rays and nobody asked for counts: the level count is known
-                // (one) and the call stays asynchronous
+            if (single_level_async) {
+                // the level count is known (one) and the call stays asynchronous
                 ++lvl;
                 break;
             }
-            HIP_TRY(hipMemcpyAsync(sc->h_counters, sc->d_counters, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpyAsync(sc->h_counters, d_counters, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            if ((rc = check_fault(sc, s)) != RT_OK) return rc;      // synchronises the stream
             HIP_TRY(hipGetLastError());
             if (timing) {
                 float a = 0, b = 0;
@@ -495,12 +620,13 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
                 return fail(RT_ERR_UNSUPPORTED, "a level of the ray tree exceeds 2^31 light-ray items; render a smaller rectangle");
             rc = ensure_level(sc->lv[lvl], kids, nl, false, two_pass);
             if (rc != RT_OK) return rc;
-            rt::launch_spawn(D, P, L, sc->lv[lvl].L, n, sc->d_counters + 1, s);
+            rt::launch_spawn(D, P, L, sc->lv[lvl].L, n, d_counters + 1, s);
             n = kids;
         }
         max_levels = std::max(max_levels, lvl);
         rt::LevelSet ls{};
-        for (int q = 0; q < lvl; ++q) ls.lv[q] = sc->lv[q].L;
+        ls.lv[0] = level0;
+        for (int q = 1; q < lvl; ++q) ls.lv[q] = sc->lv[q].L;
         if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
         const int64_t n0 = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;
         if (two_pass) rt::launch_shade_sum(D, P, ls, n0, n_pix, d_out + (int64_t)by * rw * 3, s);
@@ -514,22 +640,40 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
         }
     }
     HIP_TRY(hipGetLastError());
-    if (timing) HIP_TRY(hipEventRecord(ev_end, s));
+    if (timing) HIP_TRY(hipEventRecord(sc->ev[5], s));
     if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(rgb_out, d_out, (size_t)rw * rh * 12, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if ((rc = check_fault(sc, s)) != RT_OK) return rc;          // synchronises the stream
     }
     if (timing) {
-        HIP_TRY(hipEventSynchronize(ev_end));
-        HIP_TRY(hipEventElapsedTime(&ms_total, ev_begin, ev_end));
-        (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end);
+        HIP_TRY(hipEventSynchronize(sc->ev[5]));
+        HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev[4], sc->ev[5]));
         stats->rays_closest = rays_closest; stats->rays_any = rays_any;
         stats->ref_get_hit_calls = 2 * rays_closest + rays_any;
         stats->ms_total = ms_total; stats->ms_extend = ms_extend; stats->ms_shadow = ms_shadow; stats->ms_shade = ms_shade;
         stats->levels = max_levels;
         stats->nodes_extend = work[0]; stats->tris_extend = work[1]; stats->nodes_shadow = work[2]; stats->tris_shadow = work[3];
     }
-    return RT_OK;
+    return workspace_end(sc, s);
+}
+
+int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render_rect: null argument");
+    DeviceGuard dg(sc->device);
+    if (!dg.ok) return fail(RT_ERR_HIP, "rt_render_rect: cannot make the scene's device current");
+    RT_API_BEGIN
+    return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, nullptr);
+    RT_API_END("rt_render_rect")
+}
+
+int rt_render_rect_noalloc(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render_rect_noalloc: null argument");
+    DeviceGuard dg(sc->device);
+    if (!dg.ok) return fail(RT_ERR_HIP, "rt_render_rect_noalloc: cannot make the scene's device current");
+    FixedWorkspace fw{nullptr, RT_SCRATCH_BYTES};
+    int rc = scratch_address(sc->device, &fw.base);     // looked up by rt_init; here only on a device rt_init never saw
+    if (rc != RT_OK) return rc;
+    return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, &fw);
 }
 
 int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* stream) {
@@ -537,19 +681,30 @@ int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* s
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)width * height * 3;
     const bool in_dev = is_device_ptr(rgb), out_dev = is_device_ptr(out);
-    void* tmp = nullptr;
     const float* d_in = rgb; uint8_t* d_out = out;
+    Staging* stg = nullptr;
+    std::unique_lock<std::mutex> lock;
     if (!in_dev || !out_dev) {
-        HIP_TRY(hipMalloc(&tmp, (size_t)n * 5));
-        if (!in_dev) { HIP_TRY(hipMemcpyAsync(tmp, rgb, (size_t)n * 4, hipMemcpyHostToDevice, s)); d_in = (const float*)tmp; }
-        if (!out_dev) d_out = (uint8_t*)tmp + n * 4;
+        // host images go through this device's staging buffer, kept between calls; the call holds it until its copies
+        // are done
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= RT_MAX_DEVICES) return fail(RT_ERR_UNSUPPORTED, "device index beyond RT_MAX_DEVICES");
+        stg = &g_staging[dev];
+        lock = std::unique_lock<std::mutex>(stg->mu);
+        if (stg->cap < (size_t)n * 5) {
+            if (stg->p) (void)hipFree(stg->p);
+            stg->p = nullptr; stg->cap = 0;
+            HIP_TRY(hipMalloc(&stg->p, (size_t)n * 5));
+            stg->cap = (size_t)n * 5;
+        }
+        if (!in_dev) { HIP_TRY(hipMemcpyAsync(stg->p, rgb, (size_t)n * 4, hipMemcpyHostToDevice, s)); d_in = (const float*)stg->p; }
+        if (!out_dev) d_out = (uint8_t*)stg->p + n * 4;
     }
     rt::launch_resolve_u8(d_in, width, height, d_out, s);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && !out_dev) e = hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && tmp) e = hipStreamSynchronize(s);
-    if (tmp) (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
+    if (!out_dev) HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, s));
+    if (stg) HIP_TRY(hipStreamSynchronize(s));
     return RT_OK;
 }
 

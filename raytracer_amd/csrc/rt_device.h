@@ -5,9 +5,6 @@
 #pragma once
 #include "rt_types.h"
 
-// RT_HD marks code shared by the kernels; a host-only build (used to unit-test kernel bodies without a GPU)
-// defines RT_HOST_EMULATION and supplies float4/int4/atomics itself.
-#ifndef RT_HOST_EMULATION
 #include <hip/hip_runtime.h>
 #define RT_HD __device__ __forceinline__
 #define RT_HDM __device__ __forceinline__   // the same for member functions
@@ -46,7 +43,6 @@ typedef float rt_f16 __attribute__((ext_vector_type(16)));
                                    RT_F2I(q3.x), RT_F2I(q3.y), RT_F2I(q3.z), RT_F2I(q3.w), st, o, d, rd, lo, lim); \
         }                                                                                                    \
     } while (0)
-#endif
 
 #ifndef RT_ANY_HIT_NEAR_FIRST
 #define RT_ANY_HIT_NEAR_FIRST 0   // 1: any-hit rays also visit the nearer child first (measured: no faster, and three
@@ -62,6 +58,7 @@ struct DScene {
     const float* nrm;          // [n_tris][9], traversal order
     const Material* mats;      // per material
     const int32_t* mesh_mat;   // mesh index -> material index
+    uint32_t* fault;           // one word, set to 1 by a lane whose traversal stack overflowed
     Light lights[8];
     int32_t n_lights;
     Camera cam;
@@ -249,7 +246,7 @@ RT_HD float entry_limit(float t0) { return fmaxf(t0 * 0.99999f, 0.f); }
 // Work counters of the counting kernels: steps of this lane, or (profiling build, -DRT_COUNT_WAVE_STEPS) steps of the
 // wave - only the first active lane counts, so the sum over lanes * 64 against the per-lane sum is the lane
 // utilisation of the loop.
-#if defined(RT_COUNT_WAVE_STEPS) && !defined(RT_HOST_EMULATION)
+#if defined(RT_COUNT_WAVE_STEPS)
 #define RT_COUNT_STEP(c) do { if ((int)threadIdx.x == __builtin_amdgcn_readfirstlane((int)threadIdx.x)) ++(c); } while (0)
 #else
 #define RT_COUNT_STEP(c) ++(c)
@@ -267,10 +264,13 @@ RT_HD float entry_limit(float t0) { return fmaxf(t0 * 0.99999f, 0.f); }
 struct StackLds {
     RT_LDS_PTR int32_t* lds; // this lane's column: slot s is lds[s * RT_BLOCK]
     int32_t* spill;          // RT_STACK - RT_LDS_SLOTS entries
+    uint32_t* fault;         // where an overflow is reported (the scene's fault word; the same for every lane)
     int sp;
     RT_HDM void push(int32_t v) {
         if (sp < RT_LDS_SLOTS) lds[sp * RT_BLOCK] = v;
         else if (sp < RT_STACK) spill[sp - RT_LDS_SLOTS] = v;
+        else *fault = 1u;    // the subtree is lost; the host checks tree depth against RT_STACK before any launch, so
+                             // this only fires if that check and the tree disagree, and the host then reports it
         ++sp;
     }
     RT_HDM int32_t pop() {
@@ -395,10 +395,6 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, fl
     return found;
 }
 
-#ifdef RT_HOST_EMULATION
-static bool rt_emu_mixed_octants = false;   // host build: take the code path of a wave whose lanes differ in octant
-#endif
-
 // Picks the traversal specialised for the wave's direction octant (see slab_fast).
 template <bool ANY, bool EXACT>
 RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
@@ -408,12 +404,8 @@ RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float 
     // a zero component makes (bound - e) * (1/d) a NaN where the ray's origin lies exactly in a box plane; the
     // reference's fmin/fmax then answer by their NaN-dropping order, which only the min/max form reproduces
     if (d.x == 0.f || d.y == 0.f || d.z == 0.f) oct = 8;
-#ifdef RT_HOST_EMULATION
-    if (rt_emu_mixed_octants) oct = 8;
-#else
     const int uoct = __builtin_amdgcn_readfirstlane(oct);
     oct = (__builtin_amdgcn_ballot_w64(oct != uoct) == 0) ? uoct : 8;
-#endif
     switch (oct) {
         case 0: return traverse_oct<ANY, false, 0>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
         case 1: return traverse_oct<ANY, false, 1>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);

@@ -13,7 +13,7 @@ constexpr int BLOCK = RT_BLOCK;
     __shared__ int32_t lds_stack_[RT_LDS_SLOTS * BLOCK];                              \
     int32_t stack_spill_[RT_STACK - RT_LDS_SLOTS];                                    \
     StackLds st;                                                                      \
-    st.lds = (RT_LDS_PTR int32_t*)lds_stack_ + threadIdx.x; st.spill = stack_spill_; st.sp = 0
+    st.lds = (RT_LDS_PTR int32_t*)lds_stack_ + threadIdx.x; st.spill = stack_spill_; st.fault = sc.fault; st.sp = 0
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

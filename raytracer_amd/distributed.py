@@ -26,25 +26,32 @@ def local_to_image_rows(height, world_size, rank, band_rows=8):
 class FrameGather:
     """All-gather of the ranks' row shares into whole frames, reusable across frames (buffers and index are cached)."""
 
-    def __init__(self, height, width, world_size, band_rows, device, group=None):
-        self.h, self.w, self.world, self.group = height, width, world_size, group
+    def __init__(self, height, width, world_size, band_rows, device, group=None, dtype=torch.float32, flipped=False):
+        """flipped: the ranks exchange their rows as rt_resolve_u8 writes them - top row first WITHIN the share (local
+        row l of a share of n rows sits at n-1-l) - and the assembled frame is top-down as well (the 8-bit image the
+        reference's save_jpg builds, reference src/main.cpp:157-167)."""
+        self.h, self.w, self.world, self.group, self.dtype = height, width, world_size, group, dtype
         shares = [local_to_image_rows(height, world_size, r, band_rows) for r in range(world_size)]
         self.max_rows = max(len(s) for s in shares)
         self.n_rows = [len(s) for s in shares]
-        # frame row y is row src[y] of the gathered [world * max_rows] stack
+        # output row k is row src[k] of the gathered [world * max_rows] stack; rows beyond a rank's share (padding of the
+        # shorter shares) are never referenced
         src = torch.empty(height, dtype=torch.long)
         for r, s in enumerate(shares):
             for l, y in enumerate(s):
-                src[y] = r * self.max_rows + l
+                if flipped:
+                    src[height - 1 - y] = r * self.max_rows + (len(s) - 1 - l)
+                else:
+                    src[y] = r * self.max_rows + l
         self.src = src.to(device)
         self.device = device
 
     def new_local(self):
         """A buffer for this rank's rows, padded to the largest share so that all ranks gather equal sizes."""
-        return torch.zeros((self.max_rows, self.w, 3), dtype=torch.float32, device=self.device)
+        return torch.zeros((self.max_rows, self.w, 3), dtype=self.dtype, device=self.device)
 
     def new_stack(self):
-        return torch.empty((self.world * self.max_rows, self.w, 3), dtype=torch.float32, device=self.device)
+        return torch.empty((self.world * self.max_rows, self.w, 3), dtype=self.dtype, device=self.device)
 
     def start(self, local, stack):
         """Starts the all-gather of `local` into `stack`; returns a handle to pass to finish() (None on one rank)."""

@@ -1,0 +1,76 @@
+"""The CPU oracle (and, on the GPU box, the HIP library) against what the reference itself produced for this path:
+its two shipped result images of the bunny scene, and the counts the survey measured on the compiled reference.
+These are the only reference-made pins this path has; everything else about the oracle is restatement."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+from raytracer_amd._abi import Options, RT_JITTER_HASH, RT_JITTER_OFF
+from tests import ref_image_checks as ric
+
+
+def test_oracle_matches_the_reference_result_images(oracle_mod, bunny_scene):
+    ric.run_all(oracle_mod.OracleScene(bunny_scene), bunny_scene)
+
+
+def test_a_mirrored_camera_would_be_caught(oracle_mod, bunny_scene):
+    """The checks are not vacuous: the same scene seen through a left-right mirrored camera basis fails them."""
+    sc = scenes.bunny()
+    sc.camera.side = (-sc.camera.side).astype(np.float32)
+    with pytest.raises(AssertionError):
+        ric.run_all(oracle_mod.OracleScene(sc), sc)
+    sc = scenes.bunny()
+    sc.lights[0].vec = (-sc.lights[0].vec).astype(np.float32)      # the sign src/main.cpp:369 flips
+    with pytest.raises(AssertionError):
+        ric.run_all(oracle_mod.OracleScene(sc), sc)
+
+
+def test_counts_measured_on_the_compiled_reference(oracle_mod, bunny_scene):
+    """Numbers recorded from runs of the unmodified reference objects on this scene (before this build began):
+    13 568 of 20 736 pixel-centre primary rays hit at 192x108, hfov 60; a 480x270 frame at -spp 2 -spr 3 makes about
+    2.40 M get_hit calls and draws 65.7 % of its pixels (85 184 - 85 197 over runs of the unseeded rand())."""
+    o = oracle_mod.OracleScene(bunny_scene)
+    cam = bunny_scene.camera
+    a = cam.near * np.tan(3.1415926 * 60 / 360)
+    Wq, Hq = 192, 108
+    u = (-a + 2 * a * (np.arange(Wq) + 0.5) / Wq)[None, :].repeat(Hq, 0)
+    v = (-a * Hq / Wq + 2 * a * Hq / Wq * (np.arange(Hq) + 0.5) / Hq)[:, None].repeat(Wq, 1)
+    d = u[..., None] * cam.side + v[..., None] * cam.up - cam.near * cam.w
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32).reshape(-1, 3)
+    org = np.tile(cam.pos.astype(np.float32), (len(d), 1))
+    _, tri, _ = o.trace(org, d, 1e-4, np.inf)
+    assert (tri >= 0).sum() == 13568 and len(tri) == 20736
+    opt = Options(width=480, height=270, hfov=60, spp=2, spr=3, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=1)
+    img, st, _ = o.render_frame_mt(opt, 8)
+    calls = st.rays_closest + st.rays_any
+    assert abs(calls - 2.40e6) < 0.01e6
+    drawn = int(np.isfinite(img[..., 0]).sum())
+    assert 85184 - 40 <= drawn <= 85197 + 40
+    # with the jitter terms at zero the samples sit at the pixels' lower-left corners: a few more pixels draw
+    opt.jitter_mode = RT_JITTER_OFF
+    img0, st0, _ = o.render_frame_mt(opt, 8)
+    assert abs(st0.rays_closest + st0.rays_any - 2.40e6) < 0.01e6
+    assert abs(int(np.isfinite(img0[..., 0]).sum()) - 85189) < 200
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_reference_result_images(bunny_scene):
+    import torch
+    from raytracer_amd import api
+    api.init()
+    g = api.TracerScene(bunny_scene)
+    fx = ric.load_fixture()
+    for exact in (False, True):
+        class T:
+            def trace(self, org, d, t0, t1, any_hit=False):
+                return g.trace(org, d, t0, t1, any_hit=any_hit, exact_boxes=exact)
+        ric.run_all(T(), bunny_scene, fx)
+    # the headline frame itself (pruning traversal, hash jitter, as the benchmark renders it)
+    opt = Options(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=1)
+    frame, _ = g.render_rect(opt, 0, 0, 1920, 1080)
+    ric.frame_mask_check(frame, fx)
+    # the second image's configuration: every pixel that image 2 shows lit is drawn
+    g2 = api.TracerScene(scenes.bunny(phong_surroundings=True))
+    opt2 = Options(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, jitter_mode=RT_JITTER_HASH, seed=1)
+    frame2, _ = g2.render_rect(opt2, 0, 0, 1920, 1080)
+    ric.check_silhouette(np.isfinite(frame2[..., 0])[1::2, 1::2], fx["bright2"], within1=0.93)

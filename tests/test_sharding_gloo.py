@@ -35,8 +35,15 @@ def _worker(rank, world, port, q):
     def render(k, buf):
         buf[:len(rows)] = local + float(k)
     last = run_pipelined(5, render, fg, bufs, stacks)
+    # the benchmark's default exchange: 8-bit rows as rt_resolve_u8 leaves them (top row of the SHARE first), assembled
+    # into the top-down image; the padding rows of the shorter share hold 255 and must never reach the frame
+    fg8 = FrameGather(H, W, world, BAND, "cpu", dtype=torch.uint8, flipped=True)
+    b8, s8 = fg8.new_local(), fg8.new_stack()
+    b8.fill_(255)
+    b8[:len(rows)] = (local % 251).to(torch.uint8).flip(0)
+    top_down = fg8.finish(fg8.start(b8, s8), s8)
     dist.barrier()
-    q.put((rank, frame.numpy(), last.numpy()))
+    q.put((rank, frame.numpy(), last.numpy(), top_down.numpy()))
     dist.destroy_process_group()
 
 
@@ -52,9 +59,10 @@ def test_two_ranks_reassemble_the_frame():
         p.start()
     got = {}
     for _ in procs:
-        r, a, b = q.get(timeout=120)
+        r, a, b, c = q.get(timeout=120)
         got[r] = a
         got[(r, "last")] = b
+        got[(r, "u8")] = c
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -63,3 +71,25 @@ def test_two_ranks_reassemble_the_frame():
     for r in (0, 1):
         assert (got[r] == want.numpy()).all()
         assert (got[(r, "last")] == want.numpy() + 4.0).all()
+        assert (got[(r, "u8")] == (want % 251).to(torch.uint8).flip(0).numpy()).all()
+
+
+def test_bench_starts_the_ranks_itself(monkeypatch, capsys):
+    """`python bench.py --gpus N` outside a torchrun job starts N ranks as child processes (before anything touches a GPU)
+    and relays rank 0's line; inside a job (RANK set) it must not start another."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "m", "n_gpus": 4}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("RANK", raising=False)
+    assert bench.main(["--gpus", "4", "--steps", "2", "--warmup", "1"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 4}'
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 3, stdout=""))
+    assert bench.main(["--gpus", "2"]) == 3
