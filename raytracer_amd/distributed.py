@@ -58,6 +58,15 @@ class FrameGather:
         if self.world == 1:
             stack.copy_(local)
             return None
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal of the sharded path by several ranks on ONE GPU (RCCL refuses ranks that share a device): the
+            # exchange goes through host memory, synchronously (gloo's own asynchronous staging of GPU tensors stalled
+            # with two gathers in flight)
+            h = local.cpu()
+            hs = torch.empty(stack.shape, dtype=stack.dtype)
+            dist.all_gather_into_tensor(hs.view(-1), h.view(-1), group=self.group)
+            stack.copy_(hs)
+            return None
         return dist.all_gather_into_tensor(stack.view(-1), local.view(-1), group=self.group, async_op=True)
 
     def finish(self, work, stack):

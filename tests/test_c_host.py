@@ -48,5 +48,5 @@ def test_c_host_renders_the_oracles_image(oracle_mod, bunny_scene, tmp_path):
         h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert lines["fnv64"][0] == "%016x" % h
     # the reference traces every render ray twice; the library once
-    assert int(lines["rays_closest"][0]) * 2 == st.rays_closest and int(lines["rays_any"][2]) == st.rays_any
+    assert int(lines["rays_closest"][0]) * 2 == st.rays_closest and int(lines["rays_closest"][2]) == st.rays_any
     assert lines["triangles"][0] == "7864"

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -93,3 +94,21 @@ def test_bench_starts_the_ranks_itself(monkeypatch, capsys):
     assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 4}'
     monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 3, stdout=""))
     assert bench.main(["--gpus", "2"]) == 3
+
+
+@pytest.mark.gpu
+def test_two_ranks_render_and_gather_the_real_frame_on_one_gpu():
+    """The sharded benchmark path with the real renderer: two ranks share the one GPU (gloo carries the exchange, since
+    RCCL refuses ranks on one device), each renders its interleaved bands through the C-ABI, the 8-bit rows are gathered
+    and every rank checks the assembled frame against the frame it renders whole (--verify)."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_WATCHDOG="100")
+    for gather in ("u8", "f32"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--verify", "--steps", "5", "--warmup", "3",
+                            "--gather", gather, "--no-cpu-baseline", "--no-workloads"], env=env, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["config"]["verified"] is True and line["config"]["rays_per_frame"] == 30050272

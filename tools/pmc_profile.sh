@@ -15,7 +15,7 @@ PASSES=(
 )
 i=0
 for p in "${PASSES[@]}"; do
-  timeout -s KILL 120 rocprofv3 --pmc $p --output-format csv -d "$OUT/pass$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --workload "$WL" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $p --output-format csv -d "$OUT/pass$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-workloads --workload "$WL" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; exit 1; }
   i=$((i+1))
 done
 python3 "$R/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt"; cat "$OUT/summary.txt"
