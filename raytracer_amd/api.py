@@ -33,6 +33,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RtError("%s is missing: build it with `make -C raytracer_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        # PyTorch wheels bundle their own copy of the HIP runtime.  If this library pulled in the system's copy first and
+        # torch were imported afterwards, the process would hold two runtimes and the second one finds no GPU; importing
+        # torch first makes the dynamic loader hand its copy (same soname) to this library too.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i64, f32 = C.c_void_p, C.c_int64, C.c_float
         L.rt_init.argtypes = [C.c_int]
