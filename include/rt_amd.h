@@ -206,6 +206,16 @@ int rt_render_rect_noalloc(rt_scene* scene, const rt_options* opt, int x0, int y
  * at the bottom; out is top-down.  Both host or device. */
 int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* stream);
 
+/* Replaces the file output of save_jpg (src/main.cpp:169-176, which hands the bytes to the third-party TooJpeg::writeJpeg,
+ * src/toojpeg.h:35, with isRGB = true, quality 90, downsample = false, comment "Render Result"): a baseline JFIF file,
+ * YCbCr 4:4:4, standard quantisation tables scaled by `quality` (1..100), standard Huffman tables, `comment` as a COM
+ * segment (may be NULL).  rgb is the [height][width][3] 8-bit image rt_resolve_u8 produces (HOST memory, row 0 = top).
+ * An independent encoder: decoders give the same picture within quantisation error, the byte stream is not TooJpeg's. */
+int rt_save_jpeg(const char* path, const uint8_t* rgb, int width, int height, int quality, const char* comment);
+/* The same into memory: *out_size = bytes needed / written; out may be NULL to ask for the size only. */
+int rt_encode_jpeg(const uint8_t* rgb, int width, int height, int quality, const char* comment, uint8_t* out,
+                   int64_t out_cap, int64_t* out_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
 EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
-           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_resolve_u8"]
+           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg"]
 
 
 class RtError(RuntimeError):
@@ -55,6 +55,8 @@ def lib():
                                      C.POINTER(Stats), vp]
         L.rt_render_rect_noalloc.argtypes = L.rt_render_rect.argtypes
         L.rt_resolve_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.rt_save_jpeg.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.c_char_p]
+        L.rt_encode_jpeg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, i64, C.POINTER(i64)]
         _LIB = L
     return _LIB
 
@@ -149,3 +151,12 @@ def resolve_u8(rgb, out=None, stream=None):
         out = np.empty((h, w, 3), np.uint8)
     _check(lib().rt_resolve_u8(_ptr(rgb), w, h, _ptr(out), stream), "rt_resolve_u8")
     return out
+
+
+def save_jpeg(path, img_u8, quality=90, comment="Render Result"):
+    """Writes an [H, W, 3] uint8 image (row 0 = top) the way the reference's save_jpg does (src/main.cpp:148-180):
+    baseline JPEG, quality 90, no chroma subsampling, comment "Render Result".  Host-only, needs no GPU."""
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img.shape[0], img.shape[1]
+    _check(lib().rt_save_jpeg(str(path).encode(), img.ctypes.data, w, h, int(quality), comment.encode() if comment else None),
+           "rt_save_jpeg")

@@ -223,14 +223,11 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
     if (flat.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    // RT_AMD_FAST_TREE=refined keeps the pruning traversal on the reference's trees with refined leaves (for comparisons)
-    const char* ft = getenv("RT_AMD_FAST_TREE");
-    const bool use_sah = !(ft && strcmp(ft, "refined") == 0);
+    // the tree the pruning traversal walks: surface-area heuristic, then 16-bit box planes
     rt::FlatScene fast;
-    if (use_sah) {
-        if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
-        if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    }
+    if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
+    if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    if (!rt::quantise_nodes(&fast, &err)) return fail(RT_ERR_INVALID, err);
 
     rt_scene* sc = new rt_scene();
     (void)hipGetDevice(&sc->device);
@@ -253,10 +250,11 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
         return rc;
     }
     sc->d_fast = sc->d;
-    if (use_sah && ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
-                    (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
-                    (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
-                    (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK)) {
+    sc->d_fast.nodes = nullptr;              // the pruning traversal reads the 32-byte nodes only
+    if ((rc = upload(sc, fast.qnodes.data(), fast.qnodes.size(), &sc->d_fast.qnodes)) != RT_OK ||
+        (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
+        (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
+        (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK) {
         rt_scene_destroy(sc);
         return rc;
     }
@@ -270,7 +268,8 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     memcpy(sc->d.cam.w, camera->w, 12); memcpy(sc->d.cam.side, camera->side, 12);
     sc->d.cam.near_clip = camera->near_clip; sc->d.cam.far_clip = camera->far_clip;
     sc->d_fast = sc->d;
-    sc->d_fast.nodes = fast_ptrs.nodes; sc->d_fast.tris = fast_ptrs.tris; sc->d_fast.info = fast_ptrs.info; sc->d_fast.nrm = fast_ptrs.nrm;
+    sc->d_fast.nodes = nullptr; sc->d_fast.qnodes = fast_ptrs.qnodes; sc->d_fast.grid = fast.grid;
+    sc->d_fast.tris = fast_ptrs.tris; sc->d_fast.info = fast_ptrs.info; sc->d_fast.nrm = fast_ptrs.nrm;
     sc->n_lights = n_lights;
     sc->n_tris = (int64_t)flat.tris.size();
     sc->n_inner = (int64_t)flat.nodes.size();
@@ -296,6 +295,7 @@ int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t o
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
     if (which == 1 && !rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
+    if (which == 1 && !rt::quantise_nodes(&fast, &err)) return fail(RT_ERR_INVALID, err);      // also checks containment
     const rt::FlatScene& f = which ? fast : flat;
     const int64_t nt = (int64_t)f.tris.size(), nn = (int64_t)f.nodes.size();
     if ((int64_t)f.info.size() != nt || (int64_t)f.nrm.size() != nt * 9) return fail(RT_ERR_INVALID, "tree check: array sizes differ");

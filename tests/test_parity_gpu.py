@@ -130,7 +130,10 @@ def test_render_parity(oracle_mod, case, jitter, exact):
     if bit_exact and exact:
         assert bits_equal(a, b).all()
     elif bit_exact:
-        assert bits_equal(a, b).mean() >= 0.9999
+        # the pruning traversal may differ where a ray passes exactly through an edge shared by two triangles (equal t):
+        # the reference takes whichever of the two its own boxes let it test, the pruning traversal tests both and takes
+        # the lower tie rank.  At most one pixel in ten thousand, or a single pixel of these small frames.
+        assert (~bits_equal(a, b).all(axis=-1)).sum() <= max(1, 1e-4 * W * H)
     else:
         assert np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6)
     ua, ub = oracle_mod.resolve_u8(a), api.resolve_u8(b)
@@ -284,6 +287,13 @@ def test_headless_frame_driver(oracle_mod, tmp_path):
     ppm = np.frombuffer(open(out2, "rb").read()[-54 * 96 * 3:], np.uint8).reshape(54, 96, 3)
     assert (ppm == want).all()
     assert "Samples per pixel: 4" in open(str(tmp_path / "logs.txt")).read()
+    # the reference's own output format (src/main.cpp:148-180): JPEG, quality 90, comment "Render Result"
+    from PIL import Image
+    out3 = str(tmp_path / "c.jpg")
+    assert render.main([scene_path, str(optfile), "-o", out3, "--seed", "7", "--exact"]) == 0
+    im = Image.open(out3)
+    assert im.size == (96, 54) and im.info.get("comment") == b"Render Result"
+    assert np.abs(np.asarray(im).astype(int) - want.astype(int)).mean() < 2.0
 
 
 @pytest.mark.parametrize("name", ["bunny_lambert_1080p", "bunny_phong_1080p", "mirror_room", "glass_balls"])

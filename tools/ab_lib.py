@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.path.abspath(sys.argv[1])
 for wl in sys.argv[2:] or ["bunny_lambert_1080p"]:
-    code = ("import sys; sys.path.insert(0, %r); sys.argv=['bench.py','--no-cpu-baseline','--workload',%r]; "
+    code = ("import sys; sys.path.insert(0, %r); sys.argv=['bench.py','--no-cpu-baseline','--no-workloads','--workload',%r]; "
             "from raytracer_amd import api; api.LIB_PATH=%r; import bench; bench.main()" % (ROOT, wl, lib))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     if out.returncode != 0:
