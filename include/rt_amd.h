@@ -201,6 +201,17 @@ int rt_render_rect(rt_scene* scene, const rt_options* opt, int x0, int y0, int x
 int rt_render_rect_noalloc(rt_scene* scene, const rt_options* opt, int x0, int y0, int x1, int y1,
                            float* rgb_out, rt_stats* stats, void* stream);
 
+/* Replaces renderFrame's fan-out of one frame over worker threads and its join (src/main.cpp:474-507) by a fan-out over
+ * GPUs driven from ONE host process: scenes[i] is the same scene created on GPU i (rt_init(i); rt_scene_create(...)).
+ * The frame is cut into bands of band_rows rows; band k is rendered by scenes[k % n_scenes] (sky and geometry spread
+ * evenly), each share by one rt_render_rect-equivalent call on a host thread and stream of its own, and every band is
+ * copied straight to its rows of rgb_out ([height][width][3], row 0 = bottom; host memory or memory of any of the GPUs -
+ * peer copies).  Returns when the whole frame is in place.  The result is bit-identical to one rt_render_rect of the
+ * whole frame.  stats (may be NULL): ray counts summed, times the maximum over the GPUs.  (Processes that hold one
+ * GPU each use rt_options.row_stride with rt_render_rect instead and gather the rows themselves.) */
+int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_options* opt, int band_rows,
+                          float* rgb_out, rt_stats* stats);
+
 /* Replaces the 8-bit conversion of save_jpg (src/main.cpp:157-167):
  * out[(H-1-y)*W + x][c] = max(0, min(255, (int)floor(rgb * 256.0))), NaN -> 0.  rgb is [H][W][3] with row 0
  * at the bottom; out is top-down.  Both host or device. */

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
 EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
-           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg"]
+           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_render_frame_multi", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg"]
 
 
 class RtError(RuntimeError):
@@ -54,6 +54,7 @@ def lib():
         L.rt_render_rect.argtypes = [vp, C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int, vp,
                                      C.POINTER(Stats), vp]
         L.rt_render_rect_noalloc.argtypes = L.rt_render_rect.argtypes
+        L.rt_render_frame_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), C.c_int, vp, C.POINTER(Stats)]
         L.rt_resolve_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rt_save_jpeg.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.c_char_p]
         L.rt_encode_jpeg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, i64, C.POINTER(i64)]
@@ -142,6 +143,17 @@ class TracerScene:
         _check(fn(self._h, C.byref(opt), x0, y0, x1, y1, _ptr(out),
                   C.byref(st) if st is not None else None, stream), fn.__name__)
         return out, st
+
+
+def render_frame_multi(tracers, opt, band_rows=8, out=None, stats=True):
+    """One frame rendered by several scene handles (one per GPU) from this one process; see rt_render_frame_multi."""
+    if out is None:
+        out = np.empty((opt.height, opt.width, 3), np.float32)
+    hs = (C.c_void_p * len(tracers))(*[t._h for t in tracers])
+    st = Stats() if stats else None
+    _check(lib().rt_render_frame_multi(hs, len(tracers), C.byref(opt), band_rows, _ptr(out),
+                                       C.byref(st) if st is not None else None), "rt_render_frame_multi")
+    return out, st
 
 
 def resolve_u8(rgb, out=None, stream=None):

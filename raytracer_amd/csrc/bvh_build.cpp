@@ -543,55 +543,4 @@ bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& 
     return true;
 }
 
-bool quantise_nodes(FlatScene* f, std::string* err) {
-    // grid over the union of all child boxes
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (const Node64& n : f->nodes)
-        for (int s = 0; s < 2; ++s) {
-            if ((s ? n.rref : n.lref) == RT_NONE) continue;
-            const float* b = s ? n.rbox : n.lbox;
-            for (int a = 0; a < 3; ++a) {
-                if (!(b[a] <= b[3 + a]) || !std::isfinite(b[a]) || !std::isfinite(b[3 + a])) { *err = "a box of the tree is empty or not finite"; return false; }
-                lo[a] = std::min(lo[a], (double)b[a]); hi[a] = std::max(hi[a], (double)b[3 + a]);
-            }
-        }
-    double widest = 0;
-    for (int a = 0; a < 3; ++a) widest = std::max(widest, hi[a] - lo[a]);
-    if (!(widest > 0)) widest = 1.0;
-    QuantGrid& g = f->grid;
-    for (int a = 0; a < 3; ++a) {
-        const double ext = std::max(hi[a] - lo[a], widest * 1e-6);       // a flat scene still gets a usable step
-        g.origin[a] = (float)lo[a];
-        if ((double)g.origin[a] > lo[a]) g.origin[a] = std::nextafterf(g.origin[a], -INFINITY);
-        g.step[a] = (float)((hi[a] - (double)g.origin[a] + ext * 1e-6) / 65534.0);
-        if (!(g.step[a] > 0)) g.step[a] = (float)(ext / 65534.0);
-        // a plane rebuilt in float as fma(q, step, origin) is off by at most a few units in the last place of the
-        // largest coordinate: the lower planes use an origin moved down by that much, the upper ones moved up
-        const float slack = 4.0f * 1.1920929e-7f * (float)std::max(std::fabs(lo[a]), std::fabs(hi[a]) + ext * 1e-6);
-        g.origin_lo[a] = g.origin[a] - slack; g.origin_hi[a] = g.origin[a] + slack;
-    }
-    f->qnodes.resize(f->nodes.size());
-    for (size_t i = 0; i < f->nodes.size(); ++i) {
-        const Node64& n = f->nodes[i];
-        Node32& q = f->qnodes[i];
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < 2; ++s) {
-            if ((s ? n.rref : n.lref) == RT_NONE) continue;       // never tested
-            const float* b = s ? n.rbox : n.lbox;
-            for (int a = 0; a < 3; ++a) {
-                const double o = g.origin[a], st = g.step[a];
-                long ql = (long)std::floor(((double)b[a] - o) / st), qh = (long)std::ceil(((double)b[3 + a] - o) / st);
-                while (ql > 0 && o + ql * st > (double)b[a]) --ql;
-                while (qh < 65535 && o + qh * st < (double)b[3 + a]) ++qh;
-                ql = std::max(0l, std::min(65535l, ql)); qh = std::max(0l, std::min(65535l, qh));
-                if (o + ql * st > (double)b[a] || o + qh * st < (double)b[3 + a]) { *err = "internal: a quantised box does not contain its box"; return false; }
-                w[s * 3 + a] = (uint32_t)ql | ((uint32_t)qh << 16);
-            }
-        }
-        q.lx = w[0]; q.ly = w[1]; q.lz = w[2]; q.rx = w[3]; q.ry = w[4]; q.rz = w[5];
-        q.lref = n.lref; q.rref = n.rref;
-    }
-    return true;
-}
-
 }  // namespace rt

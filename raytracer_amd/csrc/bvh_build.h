@@ -14,13 +14,7 @@ struct FlatScene {
     std::vector<float> nrm;      // [n_tris][3][3] vertex normals, same order as tris
     int n_leaves = 0;
     int max_depth = 0;           // longest chain of inner nodes from the entry to a leaf
-    std::vector<Node32> qnodes;  // filled by quantise_nodes: nodes[] with 16-bit box planes on `grid`
-    QuantGrid grid{};
 };
-
-// Fills f->qnodes and f->grid from f->nodes (using the lref/rref pair).  Every quantised box contains its float box
-// (checked); returns false with *err otherwise.
-bool quantise_nodes(FlatScene* f, std::string* err);
 
 // Builds the per-mesh trees and the top tree; returns false and fills *err on bad input.
 bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, std::string* err);

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -87,6 +88,8 @@ struct rt_scene {
                                              // [4..7] extend nodes/tris (2 x u64), [8..11] shadow nodes/tris
     uint32_t* h_counters = nullptr;          // pinned mirror
     float* d_stage = nullptr; int64_t stage_cap = 0;
+    float* d_share = nullptr; int64_t share_cap = 0;     // this GPU's rows of a frame rendered by several GPUs
+    hipStream_t own_stream = nullptr;                    // rt_render_frame_multi: one stream per scene
     void* d_io = nullptr; int64_t io_cap = 0;  // staging for rt_trace / rt_resolve_u8 host buffers
     uint32_t* d_fault = nullptr;             // set by a kernel whose traversal stack overflowed (cannot happen for a tree
                                              // that passed the depth check; read back by every synchronising call)
@@ -223,11 +226,10 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
     if (flat.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    // the tree the pruning traversal walks: surface-area heuristic, then 16-bit box planes
+    // the tree the pruning traversal walks (surface-area heuristic)
     rt::FlatScene fast;
     if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
     if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    if (!rt::quantise_nodes(&fast, &err)) return fail(RT_ERR_INVALID, err);
 
     rt_scene* sc = new rt_scene();
     (void)hipGetDevice(&sc->device);
@@ -250,8 +252,7 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
         return rc;
     }
     sc->d_fast = sc->d;
-    sc->d_fast.nodes = nullptr;              // the pruning traversal reads the 32-byte nodes only
-    if ((rc = upload(sc, fast.qnodes.data(), fast.qnodes.size(), &sc->d_fast.qnodes)) != RT_OK ||
+    if ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
         (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
         (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
         (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK) {
@@ -268,8 +269,7 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     memcpy(sc->d.cam.w, camera->w, 12); memcpy(sc->d.cam.side, camera->side, 12);
     sc->d.cam.near_clip = camera->near_clip; sc->d.cam.far_clip = camera->far_clip;
     sc->d_fast = sc->d;
-    sc->d_fast.nodes = nullptr; sc->d_fast.qnodes = fast_ptrs.qnodes; sc->d_fast.grid = fast.grid;
-    sc->d_fast.tris = fast_ptrs.tris; sc->d_fast.info = fast_ptrs.info; sc->d_fast.nrm = fast_ptrs.nrm;
+    sc->d_fast.nodes = fast_ptrs.nodes; sc->d_fast.tris = fast_ptrs.tris; sc->d_fast.info = fast_ptrs.info; sc->d_fast.nrm = fast_ptrs.nrm;
     sc->n_lights = n_lights;
     sc->n_tris = (int64_t)flat.tris.size();
     sc->n_inner = (int64_t)flat.nodes.size();
@@ -295,7 +295,6 @@ int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t o
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
     if (which == 1 && !rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
-    if (which == 1 && !rt::quantise_nodes(&fast, &err)) return fail(RT_ERR_INVALID, err);      // also checks containment
     const rt::FlatScene& f = which ? fast : flat;
     const int64_t nt = (int64_t)f.tris.size(), nn = (int64_t)f.nodes.size();
     if ((int64_t)f.info.size() != nt || (int64_t)f.nrm.size() != nt * 9) return fail(RT_ERR_INVALID, "tree check: array sizes differ");
@@ -375,6 +374,8 @@ int rt_scene_destroy(rt_scene* sc) {
     if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->h_counters) (void)hipHostFree(sc->h_counters);
     if (sc->d_stage) (void)hipFree(sc->d_stage);
+    if (sc->d_share) (void)hipFree(sc->d_share);
+    if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
     if (sc->d_io) (void)hipFree(sc->d_io);
     for (auto& e : sc->ev) if (e) (void)hipEventDestroy(e);
     delete sc;
@@ -674,6 +675,76 @@ int rt_render_rect_noalloc(rt_scene* sc, const rt_options* o, int x0, int y0, in
     int rc = scratch_address(sc->device, &fw.base);     // looked up by rt_init; here only on a device rt_init never saw
     if (rc != RT_OK) return rc;
     return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, &fw);
+}
+
+int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_options* opt, int band_rows, float* rgb_out, rt_stats* stats) {
+    if (!scenes || n_scenes <= 0 || n_scenes > RT_MAX_DEVICES || !opt || !rgb_out || band_rows < 1)
+        return fail(RT_ERR_INVALID, "rt_render_frame_multi: null argument, no scenes or band_rows < 1");
+    for (int i = 0; i < n_scenes; ++i) {
+        if (!scenes[i]) return fail(RT_ERR_INVALID, "rt_render_frame_multi: null scene handle");
+        for (int j = 0; j < i; ++j)
+            if (scenes[i] == scenes[j]) return fail(RT_ERR_INVALID, "rt_render_frame_multi: the same scene handle twice (create one per GPU)");
+    }
+    if (opt->width <= 0 || opt->height <= 0) return fail(RT_ERR_INVALID, "rt_render_frame_multi: empty image");
+    RT_API_BEGIN
+    const int W = opt->width, H = opt->height, N = n_scenes;
+    std::vector<int> rc((size_t)N, RT_OK);
+    std::vector<std::string> msg((size_t)N);
+    std::vector<rt_stats> st((size_t)N);
+    // one host thread per GPU, like the reference's one thread per tile (src/main.cpp:489-507); joined below
+    auto work = [&](int i) {
+        rt_scene* sc = scenes[i];
+        auto bad = [&](int code, const std::string& m) { rc[(size_t)i] = code; msg[(size_t)i] = m; };
+        DeviceGuard dg(sc->device);
+        if (!dg.ok) return bad(RT_ERR_HIP, "cannot make the scene's device current");
+        // local rows of share i: every N-th band of band_rows rows
+        int n_local = 0;
+        for (int y0 = i * band_rows; y0 < H; y0 += N * band_rows) n_local += std::min(band_rows, H - y0);
+        if (n_local == 0) return;
+        hipError_t e = hipSuccess;
+        {
+            std::lock_guard<std::mutex> lock(sc->mu);
+            if (!sc->own_stream) e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
+            if (e == hipSuccess && sc->share_cap < (int64_t)n_local * W * 12) {
+                if (sc->d_share) (void)hipFree(sc->d_share);
+                sc->d_share = nullptr; sc->share_cap = 0;
+                e = hipMalloc((void**)&sc->d_share, (size_t)n_local * W * 12);
+                if (e == hipSuccess) sc->share_cap = (int64_t)n_local * W * 12;
+            }
+        }
+        if (e != hipSuccess) return bad(RT_ERR_HIP, hipGetErrorString(e));
+        rt_options o = *opt;
+        o.row_stride = N; o.row_band = band_rows; o.row_phase = i;
+        const int r = render_impl(sc, &o, 0, 0, W, n_local, sc->d_share, stats ? &st[(size_t)i] : nullptr, sc->own_stream, nullptr);
+        if (r != RT_OK) return bad(r, g_err);
+        // the bands go straight to their rows of the frame (host memory, or any GPU's: peer copies over the fabric)
+        int l = 0;
+        for (int y0 = i * band_rows; y0 < H && e == hipSuccess; y0 += N * band_rows) {
+            const int rows = std::min(band_rows, H - y0);
+            e = hipMemcpyAsync(rgb_out + (size_t)y0 * W * 3, sc->d_share + (size_t)l * W * 3, (size_t)rows * W * 12, hipMemcpyDefault, sc->own_stream);
+            l += rows;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(sc->own_stream);
+        if (e != hipSuccess) return bad(RT_ERR_HIP, hipGetErrorString(e));
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < N; ++i) pool.emplace_back(work, i);
+    work(0);
+    for (auto& t : pool) t.join();
+    for (int i = 0; i < N; ++i)
+        if (rc[(size_t)i] != RT_OK) return fail(rc[(size_t)i], "rt_render_frame_multi, share " + std::to_string(i) + ": " + msg[(size_t)i]);
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        for (const rt_stats& q : st) {
+            stats->rays_closest += q.rays_closest; stats->rays_any += q.rays_any; stats->ref_get_hit_calls += q.ref_get_hit_calls;
+            stats->nodes_extend += q.nodes_extend; stats->tris_extend += q.tris_extend; stats->nodes_shadow += q.nodes_shadow; stats->tris_shadow += q.tris_shadow;
+            stats->ms_total = std::max(stats->ms_total, q.ms_total); stats->ms_extend = std::max(stats->ms_extend, q.ms_extend);
+            stats->ms_shadow = std::max(stats->ms_shadow, q.ms_shadow); stats->ms_shade = std::max(stats->ms_shade, q.ms_shade);
+            stats->levels = std::max(stats->levels, q.levels);
+        }
+    }
+    return RT_OK;
+    RT_API_END("rt_render_frame_multi")
 }
 
 int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* stream) {

@@ -44,24 +44,6 @@ typedef float rt_f16 __attribute__((ext_vector_type(16)));
         }                                                                                                    \
     } while (0)
 
-// The same for a 32-byte node of the pruning traversal (two 16-byte loads per lane, or one 8-word scalar load).
-typedef uint32_t rt_u8x __attribute__((ext_vector_type(8)));
-#define RT_QNODE_STEP(OCT, ORDER, sc, cur, st, qr, lo, lim)                                                  \
-    do {                                                                                                     \
-        const int ucur_ = __builtin_amdgcn_readfirstlane(cur);                                               \
-        if (__builtin_amdgcn_ballot_w64((cur) != ucur_) == 0) {                                              \
-            rt_u8x s_;                                                                                       \
-            const void* up_ = (const void*)((sc).qnodes + ucur_);                                            \
-            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) : "s"(up_) : "memory"); \
-            cur = qnode_step<OCT, ORDER>(s_[0], s_[1], s_[2], s_[3], s_[4], s_[5], (int32_t)s_[6], (int32_t)s_[7], st, sc, qr, lo, lim); \
-        } else {                                                                                             \
-            const uint4* np_ = reinterpret_cast<const uint4*>((sc).qnodes + (cur));                          \
-            const uint4 q0 = np_[0], q1 = np_[1];                                                            \
-            RT_KEEP4(q0); RT_KEEP4(q1);                                                                      \
-            cur = qnode_step<OCT, ORDER>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (int32_t)q1.z, (int32_t)q1.w, st, sc, qr, lo, lim); \
-        }                                                                                                    \
-    } while (0)
-
 #ifndef RT_ANY_HIT_NEAR_FIRST
 #define RT_ANY_HIT_NEAR_FIRST 0   // 1: any-hit rays also visit the nearer child first (measured: no faster, and three
                                   // more half-rate instructions per node)
@@ -77,8 +59,6 @@ struct DScene {
     const Material* mats;      // per material
     const int32_t* mesh_mat;   // mesh index -> material index
     uint32_t* fault;           // one word, set to 1 by a lane whose traversal stack overflowed
-    const Node32* qnodes;      // the pruning traversal's tree with 16-bit box planes (same indices as nodes); NULL in the
-    QuantGrid grid;            // scene record of the reference's own trees, which are only walked with exact boxes
     Light lights[8];
     int32_t n_lights;
     Camera cam;
@@ -337,52 +317,6 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
     return true;
 }
 
-// ---- the pruning traversal's box test on 16-bit planes --------------------------------------------------------------
-// What a ray carries for it.  A plane sits at  grid origin + q * grid step,  so its distance along the ray is
-//     t = (origin + q * step - o) / d = q * (step / d) + (origin - o) / d = fma(q, srd, ord):
-// one conversion and one fused multiply-add per plane.  The result is off by rounding (of step / d, of (origin - o) / d,
-// of the fma) by at most a few 1e-7 of the two terms' sizes; `on` and `of` are ord moved down / up by a bound on that,
-// used for the planes a ray enters / leaves through, so that a box can only look larger than it is.
-struct QRay {
-    V3 srd;           // grid step / d
-    V3 on, of;        // (grid origin - o) / d, moved down (entry planes) and up (exit planes) by the rounding bound
-    V3 o, rd;         // origin and 1 / d, for waves whose lanes differ in direction octant or have a zero component
-};
-RT_HD QRay make_qray(const DScene& sc, V3 o, V3 rd) {
-    QRay q;
-    q.o = o; q.rd = rd;
-    q.srd = v3(sc.grid.step[0] * rd.x, sc.grid.step[1] * rd.y, sc.grid.step[2] * rd.z);
-    const V3 ord = v3((sc.grid.origin[0] - o.x) * rd.x, (sc.grid.origin[1] - o.y) * rd.y, (sc.grid.origin[2] - o.z) * rd.z);
-    // 1 ulp of the hardware reciprocal, one rounding each of the two products and of the fma, relative to the larger of
-    // the two terms (q <= 65535): 4e-6 leaves a wide margin
-    const float k = 4e-6f;
-    const V3 eps = v3(k * (fabsf(ord.x) + 65535.f * fabsf(q.srd.x)), k * (fabsf(ord.y) + 65535.f * fabsf(q.srd.y)),
-                      k * (fabsf(ord.z) + 65535.f * fabsf(q.srd.z)));
-    q.on = vsub(ord, eps); q.of = vadd(ord, eps);
-    return q;
-}
-RT_HD float q_lo(uint32_t w) { return (float)(w & 0xffffu); }
-RT_HD float q_hi(uint32_t w) { return (float)(w >> 16); }
-
-// Is some t of [lo, lim] inside the quantised box (wx, wy, wz)?  tmin returns the entry distance, not below lo.
-// OCT as in slab_fast: < 8 when every lane of the wave has that direction octant and no zero component, which tells at
-// compile time through which plane of each axis the ray enters; 8 rebuilds the planes in float (lower planes from an
-// origin moved down by the rounding slack, upper ones up) and takes the general test.
-template <int OCT>
-RT_HD bool slab_quant(uint32_t wx, uint32_t wy, uint32_t wz, const DScene& sc, const QRay& r, float lo, float lim, float& tmin) {
-    if (OCT < 8) {
-        const float nx = fmaf((OCT & 1) ? q_hi(wx) : q_lo(wx), r.srd.x, r.on.x), fx = fmaf((OCT & 1) ? q_lo(wx) : q_hi(wx), r.srd.x, r.of.x);
-        const float ny = fmaf((OCT & 2) ? q_hi(wy) : q_lo(wy), r.srd.y, r.on.y), fy = fmaf((OCT & 2) ? q_lo(wy) : q_hi(wy), r.srd.y, r.of.y);
-        const float nz = fmaf((OCT & 4) ? q_hi(wz) : q_lo(wz), r.srd.z, r.on.z), fz = fmaf((OCT & 4) ? q_lo(wz) : q_hi(wz), r.srd.z, r.of.z);
-        tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), lo);
-        return !(tmin > fminf(fminf(fminf(fx, fy), fz), lim));
-    }
-    const float b[6] = {fmaf(q_lo(wx), sc.grid.step[0], sc.grid.origin_lo[0]), fmaf(q_lo(wy), sc.grid.step[1], sc.grid.origin_lo[1]),
-                        fmaf(q_lo(wz), sc.grid.step[2], sc.grid.origin_lo[2]), fmaf(q_hi(wx), sc.grid.step[0], sc.grid.origin_hi[0]),
-                        fmaf(q_hi(wy), sc.grid.step[1], sc.grid.origin_hi[1]), fmaf(q_hi(wz), sc.grid.step[2], sc.grid.origin_hi[2])};
-    return slab_fast<8>(b, r.o, r.rd, lo, lim, tmin);
-}
-
 // One inner node: tests both children and returns the next reference to visit (the far child is pushed when both are
 // hit; RT_NONE when the stack is empty).  The sixteen node words are passed as scalars so that the same code serves
 // words held in vector registers and words held in scalar registers (a node the whole wave fetched once).
@@ -409,23 +343,6 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
     return st.sp ? st.pop() : RT_NONE;
 }
 
-// The same for a 32-byte node of the pruning traversal (ORDER: visit the nearer child first).
-template <int OCT, bool ORDER>
-RT_HD int32_t qnode_step(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t rx, uint32_t ry, uint32_t rz, int32_t lref, int32_t rref,
-                         StackLds& st, const DScene& sc, const QRay& qr, float lo, float lim) {
-    float tl, tr;
-    const bool hl = slab_quant<OCT>(lx, ly, lz, sc, qr, lo, lim, tl);
-    const bool hr = slab_quant<OCT>(rx, ry, rz, sc, qr, lo, lim, tr) && (rref != RT_NONE);
-    if (hl && hr) {
-        const bool swap = ORDER && tr < tl;
-        st.push(swap ? lref : rref);
-        return swap ? rref : lref;
-    }
-    if (hl) return lref;
-    if (hr) return rref;
-    return st.sp ? st.pop() : RT_NONE;
-}
-
 // Nearest hit (ANY == false) or any hit (ANY == true) with t in [t0, t1].
 // Returns true on a hit.  Nearest: best = the candidate minimal in (t, tie rank) order, which is the reference's
 // choice among equal t (ranks: see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
@@ -438,10 +355,8 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, fl
                         uint32_t* n_nodes, uint32_t* n_tris) {
     best.t = INFINITY; best.tri = -1; best.rank = INT32_MAX; best.beta = 0.f; best.gamma = 0.f;
     V3 rd = v3(0, 0, 0);
-    // the hardware reciprocal is within one unit in the last place, well inside what the pruning box tests allow for
+    // the hardware reciprocal is within one unit in the last place, well inside what slab_fast allows for
     if (!EXACT) rd = v3(RT_RCP(d.x), RT_RCP(d.y), RT_RCP(d.z));
-    QRay qr;
-    if (!EXACT) qr = make_qray(sc, o, rd);
     const float lo = entry_limit(t0);
     st.sp = 0;
     int32_t cur = 0;
@@ -451,8 +366,7 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, fl
         while (cur >= 0) {
             if (n_nodes) RT_COUNT_STEP(*n_nodes);
             const float lim = EXACT ? INFINITY : (ANY ? t1 : prune_limit(best.t));
-            if (EXACT) RT_NODE_STEP(true, 8, false, sc.nodes, cur, st, o, d, rd, lo, lim);
-            else RT_QNODE_STEP(OCT, (!ANY || RT_ANY_HIT_NEAR_FIRST), sc, cur, st, qr, lo, lim);
+            RT_NODE_STEP(EXACT, OCT, (!ANY || RT_ANY_HIT_NEAR_FIRST), sc.nodes, cur, st, o, d, rd, lo, lim);
         }
         if (cur == RT_NONE) break;
         // ---- one leaf: a run of consecutive triangles

@@ -1,6 +1,5 @@
 // __global__ wrappers and launchers of the wavefront pipeline (bodies: rt_kernels.h).
 #include <algorithm>
-#include <cstdlib>
 
 #include "rt_launch.h"
 
@@ -178,12 +177,6 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
     const unsigned g = blocks((n_items + per_wave - 1) / per_wave * 64);
     const uint32_t n_nodes = (uint32_t)(n_items / std::max(sc.n_lights, 1));
     const FastDiv dn = make_fastdiv(n_nodes);
-    static const int exp_lds = getenv("RT_EXP_LDS") ? atoi(getenv("RT_EXP_LDS")) : 0;
-    if (exp_lds > 0 && !exact && !work) {
-        (void)hipFuncSetAttribute((const void*)k_shadow<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exp_lds);
-        k_shadow<false, false><<<g, BLOCK, exp_lds, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
-        return;
-    }
     if (work) {
         if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);
         else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);

@@ -23,20 +23,6 @@ struct alignas(16) Node64 {
     int32_t rref_fine;
 };
 
-// 32-byte inner node of the tree the pruning traversal walks: the same content as Node64 (boxes of both children, two
-// child references) with every box plane as a 16-bit step count on a per-scene grid,
-//     plane = grid origin + q * grid step        (per axis; lower planes rounded down, upper planes rounded up)
-// so that a quantised box always contains the box it stands for.  The pruning traversal only needs boxes that are
-// never too small (its answer does not depend on the tree), and a node fetch is what the traversal kernels wait for:
-// the L1 cache looks up one line per lane and 16-byte load, so a 32-byte node costs half the look-ups of a 64-byte one.
-// Words: x planes of the left child (lo | hi << 16), y, z, the same of the right child, lref, rref.
-struct alignas(32) Node32 {
-    uint32_t lx, ly, lz, rx, ry, rz;
-    int32_t lref, rref;
-};
-struct QuantGrid { float origin_lo[3], origin_hi[3], origin[3], step[3]; };   // origin -/+ the rounding slack of a
-                                                                               // plane that is rebuilt in float
-
 // 48-byte triangle, traversal order.  Edges are stored pre-subtracted exactly as Triangle::hit forms them
 // (src/geometry.cpp:268-273: a-b and a-c component-wise), so the device arithmetic is the same rounding sequence.
 struct alignas(16) Tri48 {

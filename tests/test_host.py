@@ -194,3 +194,31 @@ def test_jpeg_writer_matches_the_reference_save_path(tmp_path):
     # the reference's own result images use the same container choices
     ref = os.path.join(GOLDEN, "ref_images.npz")
     assert os.path.exists(ref)
+
+
+def test_baker_generates_smooth_normals_for_meshes_without_normals():
+    """The reference imports with GenSmoothNormals (src/main.cpp:295-301): corners at one position share the normalised
+    sum of the unit normals of the faces around it."""
+    from tools.bake_fbx import smooth_normals
+    # a pyramid: apex (0,0,1) over a square, four side faces as one indexed mesh
+    verts = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [0, 0, 1]], np.float32)
+    vert_idx = np.array([0, 1, 4, 1, 2, 4, 2, 3, 4, 3, 0, 4])
+    ends = np.tile([False, False, True], 4)
+    n = smooth_normals(verts, vert_idx, ends)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-6)
+    apex = n[[2, 5, 8, 11]]
+    assert np.allclose(apex, [0, 0, 1], atol=1e-6)                       # the four side normals sum to straight up
+    # base corner 1 belongs to faces 0 (front, normal (0,-1,1)/sqrt2) and 1 (right, (1,0,1)/sqrt2)
+    want = np.array([1, -1, 2], np.float64); want /= np.linalg.norm(want)
+    assert np.allclose(n[1], want, atol=1e-6) and np.allclose(n[3], want, atol=1e-6)
+    # a flat quad as two triangles keeps the plane normal; a zero-area face contributes nothing
+    quad = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    n = smooth_normals(quad, np.array([0, 1, 2, 0, 2, 3, 0, 0, 0]), np.tile([False, False, True], 3))
+    assert np.allclose(n[:6], [0, 0, 1], atol=1e-6)
+    # on the shipped sphere the generated normals are the shipped smooth normals to within the faceting
+    sc = Scene.load(os.path.join(GOLDEN, "unit_sphere.rtscene"))
+    m = sc.meshes[0]
+    pos = m.pos.reshape(-1, 3)
+    g = smooth_normals(pos, np.arange(len(pos)), np.tile([False, False, True], m.n_tris))
+    cosang = (g * m.nrm.reshape(-1, 3)).sum(1)
+    assert np.median(cosang) > 0.995 and cosang.min() > 0.9

@@ -392,3 +392,24 @@ def test_primary_hits_of_the_1080p_frame(oracle_mod, bunny_scene):
     assert (trio == trig).mean() >= 0.9999
     both = (trio >= 0) & (trig >= 0)
     assert (np.abs(tg[both] - to[both]) <= 1e-5 * to[both]).all()
+
+
+def test_one_process_drives_several_scene_handles():
+    """rt_render_frame_multi: one host process fans a frame out over scene handles (one per GPU; here three handles on
+    the one GPU of the test box, each on its own host thread and stream) and the bands land in the caller's frame, host
+    or device memory: bit-identical to one whole-frame call."""
+    import torch
+    sc = scenes.bunny(phong_surroundings=True)
+    gs = [api.TracerScene(sc) for _ in range(3)]
+    opt = Options(width=200, height=117, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, jitter_mode=RT_JITTER_HASH, seed=11)
+    whole, sw = gs[0].render_rect(opt, 0, 0, 200, 117)
+    for band in (8, 5):
+        got, sg = api.render_frame_multi(gs, opt, band_rows=band)
+        assert bits_equal(whole, got).all()
+        assert (sg.rays_closest, sg.rays_any) == (sw.rays_closest, sw.rays_any)
+    dev = torch.full((117, 200, 3), -1.0, dtype=torch.float32, device="cuda")
+    api.render_frame_multi(gs[:2], opt, band_rows=16, out=dev, stats=False)
+    torch.cuda.synchronize()
+    assert bits_equal(whole, dev.cpu().numpy()).all()
+    with pytest.raises(api.RtError, match="twice"):
+        api.render_frame_multi([gs[0], gs[0]], opt)

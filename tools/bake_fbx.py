@@ -185,7 +185,9 @@ def bake(path):
             poly_idx = np.concatenate([[0], np.cumsum(ends)[:-1]])
             normals = layer_values(geom, "LayerElementNormal", "Normals", "NormalsIndex", poly_idx, vert_idx, 3)
             if normals is None:
-                raise ValueError("mesh %s has no normals; smooth-normal generation is not restated" % name)
+                # the reference imports with aiProcess_GenSmoothNormals (src/main.cpp:295-301): a mesh without normals
+                # gets one normal per vertex position, averaged over the faces around it
+                normals = smooth_normals(verts, vert_idx, ends)
             cpos = xform_point(W, verts[vert_idx])
             Wn = np.linalg.inv(W.astype(np.float64)).T.astype(F)
             Wn[:3, 3] = 0
@@ -232,6 +234,48 @@ def bake(path):
     if camera is None:
         camera = Camera.look([0, 0, 5], [0, 1, 0], [0, 0, -1])
     return Scene(meshes, materials, lights, camera)
+
+
+def smooth_normals(verts, vert_idx, ends):
+    """Per polygon-vertex normals for a mesh that brings none, as Assimp's GenSmoothNormals step builds them: every
+    corner first gets its face's unit normal ((v1 - v0) x (v2 - v0) of the polygon's first three corners), then all
+    corners that sit at the same position (within 1e-5 of the mesh's bounding-box diagonal) get the normalised sum of
+    their face normals; there is no angle limit (the step's default of 175 degrees only exempts near-opposite faces, which
+    are left out of each other's sums here as well).  Zero-area faces contribute nothing."""
+    n_corner = len(vert_idx)
+    face_n = np.zeros((n_corner, 3), dtype=np.float64)
+    start = 0
+    for e in np.nonzero(ends)[0]:
+        ids = vert_idx[start:e + 1]
+        if len(ids) >= 3:
+            p0, p1, p2 = verts[ids[0]].astype(np.float64), verts[ids[1]].astype(np.float64), verts[ids[2]].astype(np.float64)
+            n = np.cross(p1 - p0, p2 - p0)
+            ln = np.linalg.norm(n)
+            if ln > 0:
+                face_n[start:e + 1] = n / ln
+        start = e + 1
+    pos = verts[vert_idx].astype(np.float64)
+    diag = np.linalg.norm(pos.max(0) - pos.min(0)) if n_corner else 0.0
+    eps = max(diag * 1e-5, 1e-30)
+    # corners at the same position: snap to a grid of the tolerance and group (neighbouring cells differ by more than
+    # the tolerance for all practical meshes; exact duplicates - the common case of an indexed mesh - always group)
+    key = np.round(pos / eps).astype(np.int64)
+    _, inv = np.unique(key, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    out = np.zeros((n_corner, 3), dtype=np.float64)
+    cos_limit = np.cos(np.radians(175.0))
+    order = np.argsort(inv, kind="stable")
+    bounds = np.nonzero(np.diff(inv[order]))[0] + 1
+    for grp in np.split(order, bounds):
+        fn = face_n[grp]
+        if len(grp) == 1:
+            out[grp] = fn
+            continue
+        ok = (fn @ fn.T) >= cos_limit                    # which neighbours each corner accepts
+        out[grp] = ok.astype(np.float64) @ fn
+    ln = np.linalg.norm(out, axis=1, keepdims=True)
+    out = np.where(ln > 0, out / np.maximum(ln, 1e-300), face_n)
+    return out.astype(F)
 
 
 def convert_material(mnode, template):
