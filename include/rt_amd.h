@@ -152,7 +152,22 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes,
                     const rt_material_desc* materials, int n_materials,
                     const rt_light_desc* lights, int n_lights,
                     const rt_camera_desc* camera, rt_scene** out);
+/* The same with build options.  RT_BUILD_TREE_ON_DEVICE: the second tree of a scene - the one the pruning traversal
+ * (exact_boxes = 0) walks, on the host a surface-area-heuristic build on a few threads - is built on the GPU instead
+ * (Morton keys, radix sort, all inner nodes in parallel, boxes bottom-up): a fraction of a second for ten million
+ * triangles, at some cost in traversal speed.  The reference's own trees (tie ranks, exact_boxes = 1) are built on the
+ * host either way.  Results do not depend on the choice.  rt_scene_create passes 0, or this flag when the environment
+ * has RT_AMD_BUILDER=device. */
+enum { RT_BUILD_TREE_ON_DEVICE = 1 };
+int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes,
+                       const rt_material_desc* materials, int n_materials,
+                       const rt_light_desc* lights, int n_lights,
+                       const rt_camera_desc* camera, uint32_t flags, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
+
+/* Downloads the tree the pruning traversal of `scene` walks and verifies it on the host like rt_tree_check (meshes: the
+ * arrays the scene was created from).  out as for rt_tree_check; out[7] = 1 when the tree was built on the device. */
+int rt_scene_check_tree(rt_scene* scene, const rt_mesh_desc* meshes, int n_meshes, int64_t out[8]);
 
 /* Shape of the flattened tree: counts[0]=triangles, [1]=inner nodes, [2]=leaves, [3]=max depth. */
 int rt_scene_info(const rt_scene* scene, int64_t counts[4]);

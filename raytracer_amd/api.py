@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
-EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
+EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_create_ex", "rt_scene_check_tree", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
            "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_render_frame_multi", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg"]
 
 
@@ -46,6 +46,9 @@ def lib():
         L.rt_last_error.restype = C.c_char_p
         L.rt_scene_create.argtypes = [C.POINTER(MeshDesc), C.c_int, C.POINTER(MaterialDesc), C.c_int,
                                       C.POINTER(LightDesc), C.c_int, C.POINTER(CameraDesc), C.POINTER(vp)]
+        L.rt_scene_create_ex.argtypes = [C.POINTER(MeshDesc), C.c_int, C.POINTER(MaterialDesc), C.c_int,
+                                         C.POINTER(LightDesc), C.c_int, C.POINTER(CameraDesc), C.c_uint32, C.POINTER(vp)]
+        L.rt_scene_check_tree.argtypes = [vp, C.POINTER(MeshDesc), C.c_int, C.POINTER(i64)]
         L.rt_scene_destroy.argtypes = [vp]
         L.rt_scene_info.argtypes = [vp, C.POINTER(i64)]
         L.rt_tree_check.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(i64)]
@@ -93,13 +96,28 @@ def _ptr(a):
 class TracerScene:
     """A scene resident on the current device: flattened tree, triangles, materials, lights, camera."""
 
-    def __init__(self, scene):
+    def __init__(self, scene, device_build=None):
+        """device_build: True builds the pruning traversal's tree on the GPU (rt_scene_create_ex with
+        RT_BUILD_TREE_ON_DEVICE), False on host threads, None leaves it to the RT_AMD_BUILDER environment variable."""
         meshes, mats, lights, cam, keep = pack_scene(scene)
         h = C.c_void_p()
-        _check(lib().rt_scene_create(meshes, len(scene.meshes), mats, len(scene.materials), lights,
-                                     len(scene.lights), C.byref(cam), C.byref(h)), "rt_scene_create")
+        if device_build is None:
+            _check(lib().rt_scene_create(meshes, len(scene.meshes), mats, len(scene.materials), lights,
+                                         len(scene.lights), C.byref(cam), C.byref(h)), "rt_scene_create")
+        else:
+            _check(lib().rt_scene_create_ex(meshes, len(scene.meshes), mats, len(scene.materials), lights,
+                                            len(scene.lights), C.byref(cam), 1 if device_build else 0, C.byref(h)), "rt_scene_create_ex")
         self._h = h
         self.scene = scene
+
+    def check_tree(self):
+        """Downloads the pruning traversal's tree and verifies its invariants on the host (rt_scene_check_tree)."""
+        meshes, _, _, _, keep = pack_scene(self.scene)
+        c = (C.c_int64 * 8)()
+        _check(lib().rt_scene_check_tree(self._h, meshes, len(self.scene.meshes), c), "rt_scene_check_tree")
+        del keep
+        return dict(tris=c[0], nodes=c[1], leaves=c[2], depth=c[3], max_leaf=c[4], reached_tris=c[5], reached_nodes=c[6],
+                    built_on_device=bool(c[7]))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -213,19 +213,63 @@ bool build_flat_scene(const rt_mesh_desc* meshes, int n_meshes, FlatScene* out, 
     out->nodes.clear(); out->tris.clear(); out->info.clear(); out->nrm.clear();
     out->n_leaves = 0; out->max_depth = 0;
     out->nodes.emplace_back();                       // node 0 = entry, filled in last
-    std::vector<Built> roots;
-    int id_base = 0;
+    std::vector<int> id_base((size_t)n_meshes + 1, 0);
     for (int mi = 0; mi < n_meshes; ++mi) {
         const rt_mesh_desc& md = meshes[mi];
         if (md.n_tris < 0 || (md.n_tris > 0 && (!md.pos || !md.nrm))) { *err = "mesh with null arrays or negative size"; return false; }
-        if (md.n_tris == 0) continue;
-        Builder b;
-        b.pos = md.pos; b.nrm = md.nrm; b.mesh_index = mi; b.id_base = id_base; b.rank_base = id_base; b.out = out;
-        b.tbox.resize(md.n_tris);
-        std::vector<int> ids(md.n_tris);
-        for (int k = 0; k < md.n_tris; ++k) { b.tbox[k] = b.tri_box(k); ids[k] = k; }
-        roots.push_back(b.build(ids, 0, 64));         // src/AABBTree.cpp:10
-        id_base += md.n_tris;
+        id_base[(size_t)mi + 1] = id_base[(size_t)mi] + md.n_tris;
+    }
+    // The reference builds one tree per mesh (src/AABBTree.cpp:10); the trees are independent, so they are built on a
+    // few host threads, each into a fragment of its own, and spliced in mesh order with shifted references.
+    struct Frag { FlatScene f; Built root; };
+    std::vector<Frag> frags((size_t)n_meshes);
+    {
+        std::atomic<int> next(0);
+        std::atomic<bool> failed(false);
+        auto work = [&]() {
+            try {
+                for (;;) {
+                    const int mi = next.fetch_add(1);
+                    if (mi >= n_meshes || failed.load()) break;
+                    const rt_mesh_desc& md = meshes[mi];
+                    if (md.n_tris == 0) continue;
+                    Builder b;
+                    b.pos = md.pos; b.nrm = md.nrm; b.mesh_index = mi; b.id_base = id_base[(size_t)mi]; b.rank_base = id_base[(size_t)mi];
+                    b.out = &frags[(size_t)mi].f;
+                    b.tbox.resize(md.n_tris);
+                    std::vector<int> ids(md.n_tris);
+                    for (int k = 0; k < md.n_tris; ++k) { b.tbox[k] = b.tri_box(k); ids[k] = k; }
+                    frags[(size_t)mi].root = b.build(ids, 0, 64);         // src/AABBTree.cpp:10
+                }
+            } catch (...) { failed.store(true); }
+        };
+        const int n_threads = (int)std::max(1u, std::min(16u, std::min((unsigned)n_meshes, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        } catch (...) { /* fewer threads than hoped for */ }
+        work();
+        for (auto& th : pool) th.join();
+        if (failed.load()) { *err = "out of host memory while building the trees"; return false; }
+    }
+    std::vector<Built> roots;
+    for (int mi = 0; mi < n_meshes; ++mi) {
+        if (meshes[mi].n_tris == 0) continue;
+        Frag& fr = frags[(size_t)mi];
+        const int32_t node_off = (int32_t)out->nodes.size(), tri_off = (int32_t)out->tris.size();
+        auto shift = [&](int32_t ref) { return ref == RT_NONE ? ref : (ref >= 0 ? ref + node_off : ~(~ref + tri_off)); };
+        for (Node64 n : fr.f.nodes) {
+            n.lref = shift(n.lref); n.rref = shift(n.rref); n.lref_fine = shift(n.lref_fine); n.rref_fine = shift(n.rref_fine);
+            out->nodes.push_back(n);
+        }
+        out->tris.insert(out->tris.end(), fr.f.tris.begin(), fr.f.tris.end());
+        out->info.insert(out->info.end(), fr.f.info.begin(), fr.f.info.end());
+        out->nrm.insert(out->nrm.end(), fr.f.nrm.begin(), fr.f.nrm.end());
+        out->n_leaves += fr.f.n_leaves;
+        Built r = fr.root;
+        r.ref = shift(r.ref); r.ref_fine = shift(r.ref_fine);
+        roots.push_back(r);
+        fr.f = FlatScene();
     }
     if (roots.empty()) { *err = "scene has no triangles"; return false; }
     Node64 entry;

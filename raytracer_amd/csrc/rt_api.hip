@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 
 #include "../../include/rt_amd.h"
 #include "bvh_build.h"
+#include "lbvh_build.h"
 #include "rt_launch.h"
 
 namespace {
@@ -78,6 +80,7 @@ struct rt_scene {
     rt::DScene d{};                          // the reference's trees (exact_boxes)
     rt::DScene d_fast{};                     // the surface-area-heuristic tree of the pruning traversal
     int64_t n_tris = 0, n_inner = 0, n_leaves = 0, max_depth = 0;
+    int64_t fast_nodes = 0; int fast_depth = 0; bool built_on_device = false;    // the pruning traversal's tree
     int n_lights = 0;
     bool any_spawning_material = false;
     std::vector<void*> owned;
@@ -213,6 +216,14 @@ int rt_init(int device) {
 
 int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_desc* materials, int n_materials,
                     const rt_light_desc* lights, int n_lights, const rt_camera_desc* camera, rt_scene** out) {
+    // RT_AMD_BUILDER=device (environment): the pruning traversal's tree is built on the GPU
+    const char* b = getenv("RT_AMD_BUILDER");
+    return rt_scene_create_ex(meshes, n_meshes, materials, n_materials, lights, n_lights, camera,
+                              (b && strcmp(b, "device") == 0) ? RT_BUILD_TREE_ON_DEVICE : 0u, out);
+}
+
+int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_material_desc* materials, int n_materials,
+                       const rt_light_desc* lights, int n_lights, const rt_camera_desc* camera, uint32_t flags, rt_scene** out) {
     if (!meshes || n_meshes <= 0 || !materials || n_materials <= 0 || !camera || !out || n_lights < 0 || (n_lights > 0 && !lights))
         return fail(RT_ERR_INVALID, "rt_scene_create: null or empty argument");
     RT_API_BEGIN
@@ -226,10 +237,14 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     std::string err;
     if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
     if (flat.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    // the tree the pruning traversal walks (surface-area heuristic)
+    // the tree the pruning traversal walks: surface-area heuristic on host threads, or (RT_BUILD_TREE_ON_DEVICE, scenes
+    // of more than a handful of triangles) a linear hierarchy built on the GPU
+    const bool on_device = (flags & RT_BUILD_TREE_ON_DEVICE) != 0 && flat.tris.size() > 16;
     rt::FlatScene fast;
-    if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
-    if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    if (!on_device) {
+        if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
+        if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    }
 
     rt_scene* sc = new rt_scene();
     (void)hipGetDevice(&sc->device);
@@ -252,13 +267,31 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
         return rc;
     }
     sc->d_fast = sc->d;
-    if ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
+    if (on_device) {
+        std::vector<int32_t> rank_of(flat.tris.size());
+        for (size_t k = 0; k < flat.tris.size(); ++k) rank_of[(size_t)flat.info[k].id] = flat.tris[k].rank;
+        rt::DeviceTree dt;
+        const auto tb0 = std::chrono::steady_clock::now();
+        const bool built = rt::build_lbvh_device(meshes, n_meshes, rank_of.data(), (int64_t)flat.tris.size(), &dt, &err);
+        if (getenv("RT_AMD_DEBUG_TREE"))
+            fprintf(stderr, "rt_amd: device tree build incl. upload of the triangles %.3f s\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
+        if (!built) {
+            rt_scene_destroy(sc);
+            return fail(RT_ERR_HIP, "device tree build: " + err);
+        }
+        sc->owned.push_back(dt.nodes); sc->owned.push_back(dt.tris); sc->owned.push_back(dt.info); sc->owned.push_back(dt.nrm);
+        sc->d_fast.nodes = dt.nodes; sc->d_fast.tris = dt.tris; sc->d_fast.info = dt.info; sc->d_fast.nrm = dt.nrm;
+        sc->fast_nodes = dt.n_nodes; sc->fast_depth = dt.max_depth;
+        if (dt.max_depth + 2 > RT_STACK) { rt_scene_destroy(sc); return fail(RT_ERR_UNSUPPORTED, "device-built tree deeper than the traversal stack"); }
+    } else if ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
         (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
         (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
         (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK) {
         rt_scene_destroy(sc);
         return rc;
-    }
+    } else { sc->fast_nodes = (int64_t)fast.nodes.size(); sc->fast_depth = fast.max_depth; }
+    sc->built_on_device = on_device;
     const rt::DScene fast_ptrs = sc->d_fast;
     sc->d.n_lights = n_lights;
     for (int i = 0; i < n_lights; ++i) {
@@ -288,14 +321,10 @@ int rt_scene_create(const rt_mesh_desc* meshes, int n_meshes, const rt_material_
     RT_API_END("rt_scene_create")
 }
 
-int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t out[8]) {
-    if (!meshes || n_meshes <= 0 || !out || (which != 0 && which != 1)) return fail(RT_ERR_INVALID, "rt_tree_check: bad argument");
-    RT_API_BEGIN
-    rt::FlatScene flat, fast;
-    std::string err;
-    if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
-    if (which == 1 && !rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
-    const rt::FlatScene& f = which ? fast : flat;
+// Invariants of a flattened tree (which != 0: the refined reference pair and run lengths): every triangle in exactly one
+// leaf, every child box holds its subtree's vertices and its children's boxes, child references in range, tie ranks a
+// permutation, depth within the traversal stack.  out as documented for rt_tree_check.
+static int verify_tree(const rt::FlatScene& f, int which, const rt_mesh_desc* meshes, int n_meshes, int64_t out[8]) {
     const int64_t nt = (int64_t)f.tris.size(), nn = (int64_t)f.nodes.size();
     if ((int64_t)f.info.size() != nt || (int64_t)f.nrm.size() != nt * 9) return fail(RT_ERR_INVALID, "tree check: array sizes differ");
     // original vertices by global triangle id
@@ -360,6 +389,21 @@ int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t o
     if (max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
     out[0] = nt; out[1] = nn; out[2] = leaves; out[3] = max_depth; out[4] = max_leaf; out[5] = reached_tris; out[6] = reached_nodes; out[7] = 0;
     return RT_OK;
+}
+
+int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t out[8]) {
+    if (!meshes || n_meshes <= 0 || !out || (which != 0 && which != 1)) return fail(RT_ERR_INVALID, "rt_tree_check: bad argument");
+    RT_API_BEGIN
+    rt::FlatScene flat, fast;
+    std::string err;
+    const bool dbg = getenv("RT_AMD_DEBUG_TREE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (!rt::build_flat_scene(meshes, n_meshes, &flat, &err)) return fail(RT_ERR_INVALID, err);
+    const double t1 = now();
+    if (which == 1 && !rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
+    if (dbg) fprintf(stderr, "rt_amd: reference trees %.2f s, surface-area trees %.2f s\n", t1 - t0, now() - t1);
+    return verify_tree(which ? fast : flat, which, meshes, n_meshes, out);
     RT_API_END("rt_tree_check")
 }
 
@@ -380,6 +424,26 @@ int rt_scene_destroy(rt_scene* sc) {
     for (auto& e : sc->ev) if (e) (void)hipEventDestroy(e);
     delete sc;
     return RT_OK;
+}
+
+int rt_scene_check_tree(rt_scene* sc, const rt_mesh_desc* meshes, int n_meshes, int64_t out[8]) {
+    if (!sc || !meshes || n_meshes <= 0 || !out) return fail(RT_ERR_INVALID, "rt_scene_check_tree: null argument");
+    DeviceGuard dg(sc->device);
+    if (!dg.ok) return fail(RT_ERR_HIP, "rt_scene_check_tree: cannot make the scene's device current");
+    RT_API_BEGIN
+    rt::FlatScene f;
+    f.nodes.resize((size_t)sc->fast_nodes); f.tris.resize((size_t)sc->n_tris); f.info.resize((size_t)sc->n_tris); f.nrm.resize((size_t)sc->n_tris * 9);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(f.nodes.data(), sc->d_fast.nodes, f.nodes.size() * sizeof(rt::Node64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.tris.data(), sc->d_fast.tris, f.tris.size() * sizeof(rt::Tri48), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.info.data(), sc->d_fast.info, f.info.size() * sizeof(rt::TriInfo), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f.nrm.data(), sc->d_fast.nrm, f.nrm.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int rc = verify_tree(f, 1, meshes, n_meshes, out);
+    if (rc != RT_OK) return rc;
+    if (out[3] != sc->fast_depth) return fail(RT_ERR_INVALID, "tree check: the recorded depth differs from the tree's");
+    out[7] = sc->built_on_device ? 1 : 0;
+    return RT_OK;
+    RT_API_END("rt_scene_check_tree")
 }
 
 int rt_scene_info(const rt_scene* sc, int64_t counts[4]) {

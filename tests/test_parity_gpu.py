@@ -413,3 +413,35 @@ def test_one_process_drives_several_scene_handles():
     assert bits_equal(whole, dev.cpu().numpy()).all()
     with pytest.raises(api.RtError, match="twice"):
         api.render_frame_multi([gs[0], gs[0]], opt)
+
+
+@pytest.mark.parametrize("name", ["bunny", "mirror_room", "field"])
+def test_device_built_tree(oracle_mod, name):
+    """The pruning traversal's tree built on the GPU (Morton keys, radix sort, parallel hierarchy, bottom-up boxes): its
+    invariants hold after download (every triangle in one leaf of at most four, boxes nested, ranks a permutation), and
+    traces and frames equal those of the host-built tree and the oracle - answers do not depend on the tree."""
+    sc = {"bunny": lambda: scenes.bunny(), "mirror_room": lambda: scenes.mirror_room(6, sphere_res=8),
+          "field": lambda: scenes.bunny_field(40, seed=11)}[name]()
+    dev, host, o = api.TracerScene(sc, device_build=True), api.TracerScene(sc, device_build=False), oracle_mod.OracleScene(sc)
+    info = dev.check_tree()
+    assert info["built_on_device"] and info["tris"] == sc.n_tris == info["reached_tris"] and info["max_leaf"] <= 4
+    assert not host.check_tree()["built_on_device"]
+    P = np.concatenate([m.pos.reshape(-1, 3)[::7] for m in sc.meshes])
+    c = P.mean(0)
+    ext = float(np.abs(P - c).max())
+    org, d = random_rays(30000, 5, center=c, spread=2.5 * ext)
+    to, trio, nro = o.trace(org, d, 1e-3, np.inf)
+    for g in (dev, host):
+        tg, trig, nrg = g.trace(org, d, 1e-3, np.inf, exact_boxes=False)
+        same = trio == trig
+        assert same.mean() >= 0.9999
+        assert bits_equal(to[same], tg[same]).all() and bits_equal(nro[same], nrg[same]).all()
+        ag, _, _ = g.trace(org, d, 1e-3, 10000.0, any_hit=True, exact_boxes=False)
+        ao, _, _ = o.trace(org, d, 1e-3, 10000.0, any_hit=True)
+        assert (ao == ag).mean() >= 0.9999
+    opt = Options(width=96, height=54, hfov=60, spp=2, spr=2, max_bounce=2, max_refrac_bounce=3, eps=1e-3,
+                  jitter_mode=RT_JITTER_HASH, seed=3, exact_boxes=0)
+    a, sa = host.render_rect(opt, 0, 0, 96, 54)
+    b, sb = dev.render_rect(opt, 0, 0, 96, 54)
+    assert (~bits_equal(a, b).all(axis=-1)).sum() <= 1
+    assert abs(sa.rays_any - sb.rays_any) <= 1e-3 * sa.rays_any
