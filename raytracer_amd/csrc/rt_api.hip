@@ -650,7 +650,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         for (;;) {
             rt::Level& L = (lvl == 0) ? level0 : sc->lv[lvl].L;
             if (!single_level_async)
-                HIP_TRY(hipMemsetAsync(d_counters, 0, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), s));
+                HIP_TRY(hipMemsetAsync(d_counters, 0, RT_N_COUNTERS * sizeof(uint32_t), s));
             if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
             rt::launch_extend(exact, D, P, L, n, d_counters, counting ? (unsigned long long*)(d_counters + 4) : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
@@ -661,7 +661,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                 ++lvl;
                 break;
             }
-            HIP_TRY(hipMemcpyAsync(sc->h_counters, d_counters, (timing ? RT_N_COUNTERS : 16) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(sc->h_counters, d_counters, RT_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             if ((rc = check_fault(sc, s)) != RT_OK) return rc;      // synchronises the stream
             HIP_TRY(hipGetLastError());
             if (timing) {
@@ -677,7 +677,8 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                     rays_any += v;
                 }
             for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); work[q] += v; }
-            const int64_t kids = sc->h_counters[0];
+            int64_t kids = 0;
+            for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) kids += sc->h_counters[rt::RT_KIDS_WORD0 + q * rt::RT_TRACED_STRIDE * 2];
             ++lvl;
             if (kids == 0) break;
             if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");

@@ -306,6 +306,44 @@ RT_HD void spawn_children(const DScene& sc, const RenderParams& P, const Level& 
     }
 }
 
+// Child k of node i alone, written to N[at] (the kernel gives every CHILD a lane, so that consecutive lanes write
+// consecutive records; the values are those of spawn_children).  first = place of the node's first child.
+RT_HD void spawn_child(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t first, uint32_t at, int64_t i, int k) {
+    const int tri = res_tri(L, i);
+    const NodeIn in = node_in(sc, P, L, i);
+    const int depth = meta_depth(in.packed);
+    const Material& M = sc.mats[res_material(sc, L, tri)];
+    const V3 d = in.d;
+    const V3 n = f4v(res_hit(L, i));
+    const V3 p = f4v(res_pos(L, i));
+    const float pp = 2.f * vdot(d, n);                                  // mirror direction, src/linmath.h:59-65
+    const V3 rd = v3(d.x - pp * n.x, d.y - pp * n.y, d.z - pp * n.z);
+    const uint32_t ck = node_child(in.key, (uint32_t)k);
+    if (M.kind == 2) {                                                  // src/render_thread.cpp:239-280
+        const V3 dk = (k < P.spr) ? split_dir(rd, P.ray_eps, P, in.key, SITE_REFLECT_SPLIT, 0, (uint32_t)k) : rd;
+        N.org[at] = mk4(p, RT_I2F((int)ck));
+        N.dir[at] = mk4(dk, in.weight);
+        int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = in.refraci; cm.w = (int)(first + P.spr);
+        N.meta[at] = cm;
+    } else {                                                            // src/render_thread.cpp:318-394
+        const float refraci = RT_I2F(in.refraci);
+        V3 td = v3(0, 0, 0);
+        const float r_theta = refract_dir(d, n, refraci, M.refractivity, td);
+        const bool both = !(r_theta <= 0);
+        const int zi = RT_F2I(M.refractivity);
+        int4 cm; cm.x = (int)i; cm.z = zi; cm.w = (int)at;
+        N.org[at] = mk4(p, RT_I2F((int)ck));
+        if (k == 0) {
+            N.dir[at] = mk4(rd, both ? r_theta * in.weight : in.weight);
+            cm.y = meta_pack(RAY_REFRACTIVE, (refraci == 1) ? P.D : depth - 1, 0);
+        } else {
+            N.dir[at] = mk4(td, (1 - r_theta) * in.weight);
+            cm.y = meta_pack(RAY_REFRACTIVE, (refraci == 1) ? P.Dr : depth - 1, 1);
+        }
+        N.meta[at] = cm;
+    }
+}
+
 // one node at a time (the kernel reserves the places of a whole wave with one atomic instead)
 RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
     const int cnt = (P.can_spawn && res_tri(L, i) >= 0) ? res_kid_count(L, i) : 0;

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Lev
     RT_DECLARE_STACK(st);
     if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     kids = wave_sum(kids);
-    if ((threadIdx.x & 63) == 0 && kids) atomicAdd(&counters[0], kids);
+    // one atomic per wave on ONE word would queue up in a single L2 channel (about 8 ns each): 64 words 128 bytes apart
+    if ((threadIdx.x & 63) == 0 && kids) atomicAdd(&counters[RT_KIDS_WORD0 + (blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE * 2], kids);
     add_work<COUNT>(work, nn, nt);
 }
 
@@ -72,12 +73,18 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     add_work<COUNT>(work, nn, nt);
 }
 
-// The children of a wave's nodes get consecutive places, in lane order, from ONE atomic per wave: neighbouring nodes of
-// the next level are then children of neighbouring pixels (rays that stay together in the tree), and the cursor sees
-// 64 times fewer atomics.
-__global__ __launch_bounds__(BLOCK) void k_spawn(DScene sc, RenderParams P, Level L, Level N, int64_t n, uint32_t* cursor) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+// The children of a workgroup's nodes get consecutive places, in node order, from ONE atomic per workgroup of 1024
+// nodes (an atomic per wave on the one cursor word queues up in a single L2 channel, about 8 ns each - more than the
+// rest of the kernel): neighbouring nodes of the next level are then children of neighbouring pixels (rays that stay
+// together in the tree).  The records are written one CHILD per lane: every parent lane notes (lane, child number) for
+// each of its places in a small LDS table, and the wave walks its places 64 at a time, so that consecutive lanes write
+// consecutive 16-byte records.
+constexpr int SPAWN_BLOCK = 1024;
+__global__ __launch_bounds__(SPAWN_BLOCK) void k_spawn(DScene sc, RenderParams P, Level L, Level N, int64_t n, uint32_t* cursor) {
+    __shared__ uint16_t owner_[SPAWN_BLOCK / 64][64 * 16];       // up to spr + 1 <= 16 children per node
+    __shared__ uint32_t wave_total_[SPAWN_BLOCK / 64], wave_base_[SPAWN_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * SPAWN_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = (i < n && res_tri(L, i) >= 0) ? (uint32_t)res_kid_count(L, i) : 0u;
     uint32_t incl = cnt;
     for (int off = 1; off < 64; off <<= 1) {
@@ -85,10 +92,25 @@ __global__ __launch_bounds__(BLOCK) void k_spawn(DScene sc, RenderParams P, Leve
         if (lane >= off) incl += up;
     }
     const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t base = 0;
-    if (lane == 0 && total) base = atomicAdd(cursor, total);
-    base = __shfl(base, 0, 64);
-    if (cnt) spawn_children(sc, P, L, N, base + incl - cnt, i);
+    if (lane == 0) wave_total_[wave] = total;
+    const uint32_t excl = incl - cnt;
+    for (uint32_t k = 0; k < cnt; ++k) owner_[wave][excl + k] = (uint16_t)(lane | (k << 8));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int w = 0; w < SPAWN_BLOCK / 64; ++w) { wave_base_[w] = sum; sum += wave_total_[w]; }
+        const uint32_t b0 = sum ? atomicAdd(cursor, sum) : 0u;
+        for (int w = 0; w < SPAWN_BLOCK / 64; ++w) wave_base_[w] += b0;
+    }
+    __syncthreads();
+    const uint32_t base = wave_base_[wave];
+    if (cnt) set_kids(L, i, (int32_t)(base + excl), (int)cnt);
+    const int64_t i0 = i - lane;                           // the wave's first node
+    for (uint32_t c = (uint32_t)lane; c < total; c += 64) {
+        const uint32_t o = owner_[wave][c];
+        const int pl = (int)(o & 0xffu), k = (int)(o >> 8);
+        spawn_child(sc, P, L, N, base + c - (uint32_t)k, base + c, i0 + pl, k);
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_replay(DScene sc, RenderParams P, LevelSet ls, int64_t n_pixels, float* rgb_out) {
@@ -186,7 +208,7 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
     }
 }
 void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s) {
-    if (n > 0) k_spawn<<<blocks(n), BLOCK, 0, s>>>(sc, P, L, N, n, cursor);
+    if (n > 0) k_spawn<<<(unsigned)((n + SPAWN_BLOCK - 1) / SPAWN_BLOCK), SPAWN_BLOCK, 0, s>>>(sc, P, L, N, n, cursor);
 }
 void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_pixels, float* rgb_out, hipStream_t s) {
     if (n_pixels > 0) k_replay<<<blocks(n_pixels), BLOCK, 0, s>>>(sc, P, ls, n_pixels, rgb_out);

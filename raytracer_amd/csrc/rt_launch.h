@@ -6,13 +6,14 @@ namespace rt {
 
 struct LevelSet { Level lv[RT_MAX_LEVELS]; };
 
-// counters[0] += number of children the level will spawn
+// counters[RT_KIDS_WORD0 + q * 32] (q = 0..63, summed by the caller) += number of children the level will spawn
 // work (may be NULL): work[0] += inner nodes fetched, work[1] += triangles tested
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
                    unsigned long long* work, hipStream_t s);
 // traced (may be NULL): light rays traced, accumulated in RT_TRACED_SLOTS counters RT_TRACED_STRIDE apart (one
 // address would serialise the per-wave atomics in one L2 channel); the caller sums the slots
-enum { RT_TRACED_SLOTS = 64, RT_TRACED_STRIDE = 16 };
+enum { RT_TRACED_SLOTS = 64, RT_TRACED_STRIDE = 16,
+       RT_KIDS_WORD0 = 16 + 2 };     // the children counts share the slots' 128-byte lines: u32 word 2 of each
 void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,
                    unsigned long long* work, hipStream_t s);
 void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s);
