@@ -445,3 +445,24 @@ def test_device_built_tree(oracle_mod, name):
     b, sb = dev.render_rect(opt, 0, 0, 96, 54)
     assert (~bits_equal(a, b).all(axis=-1)).sum() <= 1
     assert abs(sa.rays_any - sb.rays_any) <= 1e-3 * sa.rays_any
+
+
+def test_calls_on_one_handle_from_two_streams_do_not_race():
+    """Asynchronous calls on ONE scene handle from different streams share the handle's queues: each call's stream first
+    waits for the previous call's work (an event recorded at its end), so back-to-back frames with different options
+    come out as if rendered one after the other."""
+    import torch
+    g = api.TracerScene(scenes.bunny())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    optA = Options(width=640, height=360, hfov=60, spp=2, spr=3, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=1)
+    optB = Options(width=512, height=300, hfov=50, spp=3, spr=2, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=2)
+    wantA, _ = g.render_rect(optA, 0, 0, 640, 360)
+    wantB, _ = g.render_rect(optB, 0, 0, 512, 300)
+    for _ in range(3):
+        a = torch.empty((360, 640, 3), dtype=torch.float32, device="cuda")
+        b = torch.empty((300, 512, 3), dtype=torch.float32, device="cuda")
+        g.render_rect(optA, 0, 0, 640, 360, out=a, stats=False, stream=s1.cuda_stream)     # returns while the GPU works
+        g.render_rect(optB, 0, 0, 512, 300, out=b, stats=False, stream=s2.cuda_stream)
+        g.render_rect(optA, 0, 0, 640, 360, out=a, stats=False, stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert bits_equal(wantA, a.cpu().numpy()).all() and bits_equal(wantB, b.cpu().numpy()).all()
