@@ -214,24 +214,49 @@ RT_HD bool slab_exact(const float* b, V3 o, V3 d, float& tmin) {
 // The exit distance is widened by a few units in the last place (the reciprocal form is that far off), which keeps
 // a ray that passes exactly through a box corner or edge (a shared vertex of a mesh) from slipping between boxes.
 // tmin returns the entry distance, not below lo.
+// What the pruning traversal keeps per ray for its box tests: 1/d and, for the octant forms, e/d widened downwards and
+// upwards (see slab_fast).
+struct SlabRay { V3 rd, en, ef; };
+
 template <int OCT>
-RT_HD bool slab_fast(const float* b, V3 o, V3 rd, float lo, float lim, float& tmin) {
+RT_HD bool slab_fast(const float* b, V3 o, const SlabRay& r, float lo, float lim, float& tmin) {
     float tn, tf;
     if (OCT < 8) {
-        const float nx = (b[(OCT & 1) ? 3 : 0] - o.x) * rd.x, fx = (b[(OCT & 1) ? 0 : 3] - o.x) * rd.x;
-        const float ny = (b[(OCT & 2) ? 4 : 1] - o.y) * rd.y, fy = (b[(OCT & 2) ? 1 : 4] - o.y) * rd.y;
-        const float nz = (b[(OCT & 4) ? 5 : 2] - o.z) * rd.z, fz = (b[(OCT & 4) ? 2 : 5] - o.z) * rd.z;
+        // One fused multiply-add per plane, bound / d - e / d, instead of a subtraction and a multiplication.  The
+        // rounded e / d is off by up to 2^-24 of itself, which need not be small against the distance: en and ef are
+        // e / d moved by 2^-22 of itself towards a later entry plane value being smaller and an exit value being larger,
+        // so the interval only ever grows.  (No zero or tiny direction component takes this form: traverse sends those
+        // rays to OCT == 8.)
+        const float nx = fmaf(b[(OCT & 1) ? 3 : 0], r.rd.x, -r.en.x), fx = fmaf(b[(OCT & 1) ? 0 : 3], r.rd.x, -r.ef.x);
+        const float ny = fmaf(b[(OCT & 2) ? 4 : 1], r.rd.y, -r.en.y), fy = fmaf(b[(OCT & 2) ? 1 : 4], r.rd.y, -r.ef.y);
+        const float nz = fmaf(b[(OCT & 4) ? 5 : 2], r.rd.z, -r.en.z), fz = fmaf(b[(OCT & 4) ? 2 : 5], r.rd.z, -r.ef.z);
         tn = fmaxf(fmaxf(nx, ny), nz);
         tf = fminf(fminf(fx, fy), fz);
     } else {
-        const float t1 = (b[0] - o.x) * rd.x, t2 = (b[3] - o.x) * rd.x;
-        const float t3 = (b[1] - o.y) * rd.y, t4 = (b[4] - o.y) * rd.y;
-        const float t5 = (b[2] - o.z) * rd.z, t6 = (b[5] - o.z) * rd.z;
+        const float t1 = (b[0] - o.x) * r.rd.x, t2 = (b[3] - o.x) * r.rd.x;
+        const float t3 = (b[1] - o.y) * r.rd.y, t4 = (b[4] - o.y) * r.rd.y;
+        const float t5 = (b[2] - o.z) * r.rd.z, t6 = (b[5] - o.z) * r.rd.z;
         tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
     }
     tmin = fmaxf(tn, lo);
     return !(tmin > fminf(tf * 1.000001f, lim));
+}
+
+// 1/d (hardware reciprocal: within one unit in the last place, well inside what slab_fast allows for) and the widened
+// e/d.  usable_oct is false when the fused form must not be used: a component of d that is zero or so small that e/d
+// is not a moderate finite number.
+RT_HD SlabRay make_slab_ray(V3 o, V3 d, bool& usable_oct) {
+    SlabRay r;
+    r.rd = v3(RT_RCP(d.x), RT_RCP(d.y), RT_RCP(d.z));
+    const V3 ed = vmul(o, r.rd);
+    const float w = 2.384185791015625e-07f;   // 2^-22
+    const V3 m = v3(fabsf(ed.x) * w, fabsf(ed.y) * w, fabsf(ed.z) * w);
+    r.en = vadd(ed, m); r.ef = vsub(ed, m);
+    const float big = fmaxf(fmaxf(fabsf(ed.x), fabsf(ed.y)), fabsf(ed.z));
+    const float small = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    usable_oct = (big < 1e30f) && (small > 1e-18f);
+    return r;
 }
 
 // Bounds the pruning traversal hands to slab_fast.
@@ -323,7 +348,7 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
 template <bool EXACT, int OCT, bool ORDER>
 RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8,
                         float b9, float b10, float b11, int32_t r0, int32_t r1, int32_t r2, int32_t r3, StackLds& st,
-                        V3 o, V3 d, V3 rd, float lo, float lim) {
+                        V3 o, V3 d, const SlabRay& rd, float lo, float lim) {
     const float lb[6] = {b0, b1, b2, b3, b4, b5};
     const float rb[6] = {b6, b7, b8, b9, b10, b11};
     // the reference's own leaves when its exact box tests are asked for, the refined ones otherwise
@@ -351,12 +376,9 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
 // Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
 // so that the lanes of a wave run the same kind of work together.
 template <bool ANY, bool EXACT, int OCT>
-RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
+RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRay& rd, float t0, float t1, HitRec& best,
                         uint32_t* n_nodes, uint32_t* n_tris) {
     best.t = INFINITY; best.tri = -1; best.rank = INT32_MAX; best.beta = 0.f; best.gamma = 0.f;
-    V3 rd = v3(0, 0, 0);
-    // the hardware reciprocal is within one unit in the last place, well inside what slab_fast allows for
-    if (!EXACT) rd = v3(RT_RCP(d.x), RT_RCP(d.y), RT_RCP(d.z));
     const float lo = entry_limit(t0);
     st.sp = 0;
     int32_t cur = 0;
@@ -399,23 +421,26 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, fl
 template <bool ANY, bool EXACT>
 RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
                     uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    if (EXACT) return traverse_oct<ANY, true, 8>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+    SlabRay rd; rd.rd = rd.en = rd.ef = v3(0, 0, 0);
+    if (EXACT) return traverse_oct<ANY, true, 8>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+    bool usable;
+    rd = make_slab_ray(o, d, usable);
     int oct = (int)(((uint32_t)RT_F2I(d.x) >> 31) | (((uint32_t)RT_F2I(d.y) >> 31) << 1) | (((uint32_t)RT_F2I(d.z) >> 31) << 2));
     // a zero component makes (bound - e) * (1/d) a NaN where the ray's origin lies exactly in a box plane; the
     // reference's fmin/fmax then answer by their NaN-dropping order, which only the min/max form reproduces
-    if (d.x == 0.f || d.y == 0.f || d.z == 0.f) oct = 8;
+    if (!usable) oct = 8;
     const int uoct = __builtin_amdgcn_readfirstlane(oct);
     oct = (__builtin_amdgcn_ballot_w64(oct != uoct) == 0) ? uoct : 8;
     switch (oct) {
-        case 0: return traverse_oct<ANY, false, 0>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 1: return traverse_oct<ANY, false, 1>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 2: return traverse_oct<ANY, false, 2>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 3: return traverse_oct<ANY, false, 3>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 4: return traverse_oct<ANY, false, 4>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 5: return traverse_oct<ANY, false, 5>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 6: return traverse_oct<ANY, false, 6>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        case 7: return traverse_oct<ANY, false, 7>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
-        default: return traverse_oct<ANY, false, 8>(sc, st, o, d, t0, t1, best, n_nodes, n_tris);
+        case 0: return traverse_oct<ANY, false, 0>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 1: return traverse_oct<ANY, false, 1>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 2: return traverse_oct<ANY, false, 2>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 3: return traverse_oct<ANY, false, 3>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 4: return traverse_oct<ANY, false, 4>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 5: return traverse_oct<ANY, false, 5>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 6: return traverse_oct<ANY, false, 6>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 7: return traverse_oct<ANY, false, 7>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        default: return traverse_oct<ANY, false, 8>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
     }
 }
 
