@@ -108,6 +108,9 @@ def parse_args(argv):
     ap.add_argument("--workload", default="bunny_lambert_1080p", choices=WORKLOAD_NAMES)
     ap.add_argument("--gather", default="u8", choices=["u8", "f32"],
                     help="what the ranks exchange per frame: the 8-bit rows (what the reference's save_jpg consumes) or the float rows")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="scene handles / HIP streams that consecutive frames alternate over (0: 1 on one GPU, 3 when the "
+                         "frame is shared by several ranks - a rank's share is too small to keep its GPU busy by itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the per-configuration frame times of the other workloads")
     ap.add_argument("--verify", action="store_true",
@@ -148,27 +151,32 @@ def main(argv=None):
     scene = make()
     opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=0, **kw)
     W, H = opt.width, opt.height
-    tracer = api.TracerScene(scene)
+    n_streams = args.streams if args.streams > 0 else (1 if world == 1 else 3)
+    tracers = [api.TracerScene(scene) for _ in range(n_streams)]      # calls on one handle serialise: a handle per stream
+    tracer = tracers[0]
     stream = torch.cuda.current_stream().cuda_stream
+    side_streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else None
+    n_sets = max(2, n_streams)
     # this rank's share: every world-th band of BAND_ROWS rows, rendered by ONE call per frame
     n_local = len(local_to_image_rows(H, world, rank, BAND_ROWS)) if world > 1 else H
     if world > 1:
         opt.row_stride, opt.row_band, opt.row_phase = world, BAND_ROWS, rank
     u8 = args.gather == "u8"
     gather = FrameGather(H, W, world, BAND_ROWS, dev, dtype=torch.uint8 if u8 else torch.float32, flipped=u8) if world > 1 else None
-    # two sets of buffers: the gather of frame k overlaps the rendering of frame k+1
-    rgb = [torch.empty((max(n_local, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
-    bytes_ = [(gather.new_local() if (gather and u8) else torch.empty((max(n_local, 1), W, 3), dtype=torch.uint8, device=dev)) for _ in range(2)]
-    locals_ = bytes_ if u8 else ([gather.new_local() for _ in range(2)] if gather else rgb)
+    # n_sets sets of buffers: the gather of frame k overlaps the rendering of the next frames
+    rgb = [torch.empty((max(n_local, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    bytes_ = [(gather.new_local() if (gather and u8) else torch.empty((max(n_local, 1), W, 3), dtype=torch.uint8, device=dev)) for _ in range(n_sets)]
+    locals_ = bytes_ if u8 else ([gather.new_local() for _ in range(n_sets)] if gather else rgb)
     if gather and not u8:
         rgb = locals_
-    stacks = [gather.new_stack() if gather else None for _ in range(2)]
+    stacks = [gather.new_stack() if gather else None for _ in range(n_sets)]
 
     def render(k, stats=False):
-        b = k % 2
-        st = tracer.render_rect(opt, 0, 0, W, n_local, out=rgb[b][:n_local], stats=stats, stream=stream)[1]
+        b = k % n_sets
+        cur = torch.cuda.current_stream().cuda_stream
+        st = tracers[b % n_streams].render_rect(opt, 0, 0, W, n_local, out=rgb[b][:n_local], stats=stats, stream=cur)[1]
         # the reference's save path converts the frame to bytes (src/main.cpp:157-167); every rank converts its rows
-        api.resolve_u8(rgb[b][:n_local], out=bytes_[b][:n_local], stream=stream)
+        api.resolve_u8(rgb[b][:n_local], out=bytes_[b][:n_local], stream=cur)
         return st
 
     # rays per frame (the same every step: the seed is fixed)
@@ -181,9 +189,13 @@ def main(argv=None):
     def run(steps):
         if not gather:
             for k in range(steps):
-                render(k)
-            return bytes_[(steps - 1) % 2]
-        return run_pipelined(steps, lambda k, buf: render(k), gather, locals_, stacks)
+                if side_streams:
+                    with torch.cuda.stream(side_streams[k % n_streams]):
+                        render(k)
+                else:
+                    render(k)
+            return bytes_[(steps - 1) % n_sets]
+        return run_pipelined(steps, lambda k, buf: render(k), gather, locals_, stacks, side_streams)
 
     run(args.warmup)
     if world > 1:
@@ -226,8 +238,10 @@ def main(argv=None):
         "config": {"workload": args.workload, "width": W, "height": H, "spp": opt.spp * opt.spp, "spr": opt.spr + 1,
                    "max_bounce": opt.max_bounce, "triangles": scene.n_tris, "lights": len(scene.lights),
                    "rays_per_frame": int(rays_frame),
-                   "sharding": ("%d-row bands interleaved over ranks, one all_gather of the %s rows per frame, overlapped with the next frame"
-                                % (BAND_ROWS, "8-bit" if u8 else "float")) if world > 1 else "none",
+                   "sharding": ("%d-row bands interleaved over ranks, one all_gather of the %s rows per frame, overlapped with the "
+                                "next frames; consecutive frames alternate over %d streams per rank"
+                                % (BAND_ROWS, "8-bit" if u8 else "float", n_streams)) if world > 1 else "none",
+                   "streams": n_streams,
                    "verified": bool(args.verify)},
         "ms_per_frame": round(ms_per_step, 4),
     }

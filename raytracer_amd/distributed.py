@@ -76,26 +76,48 @@ class FrameGather:
         return stack.index_select(0, self.src)
 
 
-def run_pipelined(steps, render, gather, locals_, stacks):
-    """Renders `steps` frames with render(k, local_buffer) and gathers each one; the gather of frame k runs while frame
-    k+1 renders (two sets of buffers).  Returns the last whole frame (None when steps == 0).
+def run_pipelined(steps, render, gather, locals_, stacks, streams=None):
+    """Renders `steps` frames with render(k, local_buffer) and gathers each one.  Frame k uses buffer set k % n
+    (n = len(locals_) >= 2), so the gather of frame k runs while the next frames render.  With `streams` (one
+    torch.cuda.Stream per set) frame k is rendered, gathered and reordered on stream k % n: consecutive frames then
+    overlap on the GPU as well, which is what keeps it busy when a rank's share of a frame is small (a kernel over an
+    eighth of a frame is mostly ramp-up and tail).  Every rank issues its gathers in frame order.
+    Returns the last whole frame (None when steps == 0).
 
-    render(k, buf) must enqueue its work on the current stream; gather is a FrameGather."""
-    pending = [None, None]
+    render(k, buf) must enqueue its work on the stream that is current when it is called; gather is a FrameGather."""
+    n = len(locals_)
+    pending = [None] * n
     frame = None
+
+    def on(b):
+        return torch.cuda.stream(streams[b]) if streams else _NullContext()
+
     for k in range(steps):
-        b = k % 2
-        if pending[b] is not None:                      # buffers of frame k-2 are free once its gather has finished
-            frame = gather.finish(pending[b][0], stacks[b])
-            pending[b] = None
-        render(k, locals_[b])
-        pending[b] = (gather.start(locals_[b], stacks[b]),)
-    for k in (steps, steps + 1):                        # drain in frame order
-        b = k % 2
+        b = k % n
+        with on(b):
+            if pending[b] is not None:                  # the buffers of frame k-n are free once its gather has finished
+                frame = gather.finish(pending[b][0], stacks[b])
+                pending[b] = None
+            render(k, locals_[b])
+            pending[b] = (gather.start(locals_[b], stacks[b]),)
+    for k in range(steps, steps + n):                   # drain in frame order
+        b = k % n
         if pending[b] is not None:
-            frame = gather.finish(pending[b][0], stacks[b])
+            with on(b):
+                frame = gather.finish(pending[b][0], stacks[b])
             pending[b] = None
+    if streams:
+        for st in streams:                              # the caller's stream continues after every frame is complete
+            torch.cuda.current_stream().wait_stream(st)
     return frame
+
+
+class _NullContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 def gather_frame(local_rows, height, width, world_size, band_rows=8, group=None):
