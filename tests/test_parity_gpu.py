@@ -84,6 +84,34 @@ def test_trace_edge_cases(oracle_mod, bunny_scene):
                 assert same[1:].all() and (tg[~same] < to[~same]).all()
 
 
+def test_zero_area_triangle_in_a_mesh_of_its_own(oracle_mod):
+    """A triangle whose three corners coincide makes Triangle::hit divide 0 by 0: t is NaN, which passes every
+    comparison of the test, and get_hit never keeps such a record (reference src/render_thread.cpp:15).  With the
+    degenerate triangle in a mesh of its own the reference's answer is well defined - the ray goes on to whatever lies
+    behind - and the GPU must give it in both box modes: for batches of rays and inside a frame."""
+    from tests.test_oracle import one_mesh_scene
+    from raytracer_amd.scene import Mesh, Light
+    real = [[-1, -1, 0], [1, -1, 0], [0, 1, 0]]
+    sc = one_mesh_scene([real], lights=[Light(0, np.array([0, 0, 1], np.float32), np.array([1, 1, 1], np.float32))])
+    pt = np.array([[[0.25, 0.25, 0.5]] * 3], np.float32)
+    sc.meshes.insert(0, Mesh("speck", 0, pt, np.tile(np.array([0, 0, 1], np.float32), (1, 3, 1))))
+    g, o = _pair(sc, oracle_mod)
+    org = np.array([[0.25, 0.25, 1.0], [0.25, 0.25, 1.0], [0.0, 0.0, 2.0], [0.25, 0.25, 0.75]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0.125, 0.125, -0.75], [0, 0, -1]], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    to, trio, _ = o.trace(org, d, 1e-4, np.inf)
+    assert trio[0] == 1 and trio[1] == -1 and trio[2] == 1        # the speck is never the answer
+    for exact in (True, False):
+        tg, trig, _ = g.trace(org, d, 1e-4, np.inf, exact_boxes=exact)
+        assert (trig == trio).all() and bits_equal(tg, to).all()
+        hit_any, _, _ = g.trace(org, d, 1e-4, np.inf, any_hit=True, exact_boxes=exact)
+        assert (np.isfinite(hit_any) == (trio >= 0)).all()
+        opt = Options(width=48, height=32, hfov=40, spp=2, spr=2, max_bounce=2, jitter_mode=RT_JITTER_OFF, exact_boxes=int(exact))
+        img_o = o.render_rect(opt, 0, 0, 48, 32)[0]
+        img_g = g.render_rect(opt, 0, 0, 48, 32)[0]
+        assert bits_equal(img_o, img_g).all()
+
+
 def test_tie_rules_on_gpu(oracle_mod):
     from tests.test_oracle import one_mesh_scene
     from raytracer_amd.scene import Mesh
