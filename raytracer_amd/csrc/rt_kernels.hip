@@ -15,9 +15,18 @@ constexpr int BLOCK = RT_BLOCK;
     StackLds st;                                                                      \
     st.lds = (RT_LDS_PTR int32_t*)lds_stack_ + threadIdx.x; st.spill = stack_spill_; st.fault = sc.fault; st.sp = 0
 
+// Sum over the 64 lanes, the same value returned to every lane.  Lane-to-lane adds inside the vector ALU (a running sum
+// along each row of 16 lanes, then the row totals carried into the following rows) instead of six exchanges through the
+// LDS crossbar; the total ends up in lane 63.
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
 // work[0] += inner nodes fetched, work[1] += triangles tested (COUNT builds only)
@@ -35,6 +44,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Lev
     uint32_t kids = 0, nn = 0, nt = 0;
     RT_DECLARE_STACK(st);
     if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    if (!P.can_spawn) { add_work<COUNT>(work, nn, nt); return; }     // no material of the scene spawns rays: nothing to count
     kids = wave_sum(kids);
     // one atomic per wave on ONE word would queue up in a single L2 channel (about 8 ns each): 64 words 128 bytes apart
     if ((threadIdx.x & 63) == 0 && kids) atomicAdd(&counters[RT_KIDS_WORD0 + (blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE * 2], kids);
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     const unsigned long long mask = __ballot(reached);
     if (did && k == 0) store_unocc(sc, P, L, w, (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull)));
     if (traced) {
-        did = wave_sum(did);
+        did = (uint32_t)__popcll(__ballot(did != 0));
         if (lane == 0 && did) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE], (unsigned long long)did);
     }
     add_work<COUNT>(work, nn, nt);
