@@ -36,6 +36,10 @@ def _worker(rank, world, port, q):
     def render(k, buf):
         buf[:len(rows)] = local + float(k)
     last = run_pipelined(5, render, fg, bufs, stacks)
+    # the same with three frames in flight (what the benchmark does on several ranks: a buffer set per stream)
+    bufs3, stacks3 = [fg.new_local() for _ in range(3)], [fg.new_stack() for _ in range(3)]
+    last3 = run_pipelined(7, render, fg, bufs3, stacks3)
+    assert torch.equal(last3, last + 2.0)
     # the benchmark's default exchange: 8-bit rows as rt_resolve_u8 leaves them (top row of the SHARE first), assembled
     # into the top-down image; the padding rows of the shorter share hold 255 and must never reach the frame
     fg8 = FrameGather(H, W, world, BAND, "cpu", dtype=torch.uint8, flipped=True)
