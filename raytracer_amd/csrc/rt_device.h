@@ -144,6 +144,15 @@ RT_HD int rnd(int jitter, uint32_t seed, uint32_t node, uint32_t site, uint32_t 
     if (jitter == 0) return 100;
     return (int)(h_fin(h_mix(h_mix(h_mix(h_mix(seed, node), site), a), b)) >> 1);
 }
+// rand() at call sites (a, b0), (a, b0 + 1), (a, b0 + 2) of one node - the three components of a jitter vector: the
+// same values as three rnd() calls, with the part of the hash they share computed once and one test of the mode.
+RT_HD void rnd3(int jitter, uint32_t seed, uint32_t node, uint32_t site, uint32_t a, uint32_t b0, int& r0, int& r1, int& r2) {
+    if (jitter == 0) { r0 = r1 = r2 = 100; return; }
+    const uint32_t pre = h_mix(h_mix(h_mix(seed, node), site), a);
+    r0 = (int)(h_fin(h_mix(pre, b0)) >> 1);
+    r1 = (int)(h_fin(h_mix(pre, b0 + 1u)) >> 1);
+    r2 = (int)(h_fin(h_mix(pre, b0 + 2u)) >> 1);
+}
 RT_HD uint32_t node_root(uint32_t seed, uint32_t pixel, uint32_t sample) {
     return h_fin(h_mix(h_mix(seed ^ 0x5bd1e995u, pixel), sample));
 }
@@ -164,8 +173,10 @@ RT_HD float div100(float x) {
 RT_HD V3 primary_dir(const DScene& sc, const RenderParams& P, int i, int j, int s, uint32_t node) {
     const int x = (int)fdiv((uint32_t)s, P.div_spp), y = s - x * P.spp;
     const float unit_len = 1.0f / P.spp;
-    const float jx = div100((float)(rnd(P.jitter, P.seed, node, SITE_PRIMARY, 0, 0) % 100));
-    const float jy = div100((float)(rnd(P.jitter, P.seed, node, SITE_PRIMARY, 0, 1) % 100));
+    int r0, r1, r2;
+    rnd3(P.jitter, P.seed, node, SITE_PRIMARY, 0, 0, r0, r1, r2);    // the third value is not used (and not computed)
+    const float jx = div100((float)(r0 % 100));
+    const float jy = div100((float)(r1 % 100));
     const float u = P.fl + (P.fr - P.fl) * (i + unit_len * x + jx * unit_len) / P.W;
     const float v = P.fb + (P.ft - P.fb) * (j + unit_len * y + jy * unit_len) / P.H;
     V3 du = vscale(v3p(sc.cam.side), u), dv = vscale(v3p(sc.cam.up), v), dw = vscale(v3p(sc.cam.w), -P.fd);
@@ -177,17 +188,21 @@ RT_HD V3 light_dir(const Light& L, V3 p, const RenderParams& P, uint32_t node, u
     if (L.kind == 0) return v3p(L.vec);
     V3 r = vnorm(vsub(v3p(L.vec), p));
     V3 add;
-    add.x = 0.01f * (div100((float)(rnd(P.jitter, P.seed, node, site, li, 0) % 200)) - 1.0f);
-    add.y = 0.01f * (div100((float)(rnd(P.jitter, P.seed, node, site, li, 1) % 200)) - 1.0f);
-    add.z = 0.01f * (div100((float)(rnd(P.jitter, P.seed, node, site, li, 2) % 200)) - 1.0f);
+    int r0, r1, r2;
+    rnd3(P.jitter, P.seed, node, site, li, 0, r0, r1, r2);
+    add.x = 0.01f * (div100((float)(r0 % 200)) - 1.0f);
+    add.y = 0.01f * (div100((float)(r1 % 200)) - 1.0f);
+    add.z = 0.01f * (div100((float)(r2 % 200)) - 1.0f);
     return vnorm(vadd(r, add));
 }
 // src/ray.cpp:47-61: one jittered copy of an exact direction
 RT_HD V3 split_dir(V3 exact, float eps, const RenderParams& P, uint32_t node, uint32_t site, uint32_t a, uint32_t k) {
     V3 add;
-    add.x = eps * (div100((float)(rnd(P.jitter, P.seed, node, site, a, k * 3 + 0) % 200)) - 1.0f);
-    add.y = eps * (div100((float)(rnd(P.jitter, P.seed, node, site, a, k * 3 + 1) % 200)) - 1.0f);
-    add.z = eps * (div100((float)(rnd(P.jitter, P.seed, node, site, a, k * 3 + 2) % 200)) - 1.0f);
+    int r0, r1, r2;
+    rnd3(P.jitter, P.seed, node, site, a, k * 3, r0, r1, r2);
+    add.x = eps * (div100((float)(r0 % 200)) - 1.0f);
+    add.y = eps * (div100((float)(r1 % 200)) - 1.0f);
+    add.z = eps * (div100((float)(r2 % 200)) - 1.0f);
     return vnorm(vadd(exact, add));
 }
 
