@@ -35,8 +35,8 @@ struct alignas(64) NodeRec {
                                       // later stages want from the triangle, and three dependent loads nearer)
     float aux;                        // Schlick term r_theta of a refractive spawn
     int32_t comp;                     // node (this level) whose ray the companion shadow ray repeats
-    uint8_t unocc[8];                 // per light: light rays that reached it, out of spr+1 (written by shadow, only
-                                      // where the companion shadow ray hit)
+    uint8_t unocc[8];                 // per light: light rays that reached it, out of spr+1; RT_NO_COMPANION_HIT where
+                                      // the companion shadow ray hit nothing and none was traced (written by shadow)
 };
 enum { REC_SAME_MEDIUM = 1 << 21 };   // the ray travels in the hit material's own medium (refraci == refractivity)
 
@@ -226,6 +226,10 @@ RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, 
     return true;
 }
 
+// Count byte of an item whose companion ray hit nothing (no light ray is traced, the reference keeps the stale shadow
+// record, src/render_thread.cpp:134): larger than any count (at most spr + 1 <= 16).  The replay reads it instead of
+// fetching the companion's record - one dependent load less per node of a walk that is all dependent loads.
+enum { RT_NO_COMPANION_HIT = 255 };
 RT_HD void store_unocc(const DScene& sc, const RenderParams& P, const Level& L, int64_t w, uint32_t unocc) {
     if (L.implicit) { L.unocc[w] = (uint8_t)unocc; return; }
     const uint32_t i = fdiv((uint32_t)w, P.div_lights);
@@ -246,7 +250,7 @@ template <bool EXACT>
 RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t w,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     ShadowItem it;
-    if (!shadow_item(sc, P, L, w, it)) return 0;
+    if (!shadow_item(sc, P, L, w, it)) { if (!L.implicit) store_unocc(sc, P, L, w, RT_NO_COMPANION_HIT); return 0; }
     uint32_t unocc = 0;
     for (int k = 0; k <= P.spr; ++k) unocc += shadow_ray<EXACT>(sc, P, it, st, k, n_nodes, n_tris) ? 1u : 0u;
     store_unocc(sc, P, L, w, unocc);
@@ -442,8 +446,8 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
             head = *reinterpret_cast<const int4*>(&R->kid_base);
             const int4 tail = *reinterpret_cast<const int4*>(&R->aux);
             aux = RT_I2F(tail.x);
-            comp_tri = L.rec[tail.y].tri;
             un_lo = (uint32_t)tail.z; un_hi = (uint32_t)tail.w;
+            comp_tri = ((un_lo & 255u) == (uint32_t)RT_NO_COMPANION_HIT) ? -1 : 0;   // what the light-ray kernel noted
         }
         const int type = meta_type(head.y), depth = meta_depth(head.y), n_kids = (int)((uint32_t)head.y >> 24);
         const float weight = RT_I2F(head.z);

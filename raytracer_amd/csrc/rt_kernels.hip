@@ -70,12 +70,15 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     bool reached = false;
     RT_DECLARE_STACK(st);
     ShadowItem it;
-    if (sub < per_wave && v < n_items && shadow_item(sc, P, L, w, it)) {
+    const bool item = sub < per_wave && v < n_items;
+    if (item && shadow_item(sc, P, L, w, it)) {
         did = 1;
         reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     }
     const unsigned long long mask = __ballot(reached);
     if (did && k == 0) store_unocc(sc, P, L, w, (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull)));
+    // below level 0 the replay learns from the count byte itself that the companion ray missed (RT_NO_COMPANION_HIT)
+    else if (item && k == 0 && !L.implicit) store_unocc(sc, P, L, w, RT_NO_COMPANION_HIT);
     if (traced) {
         did = (uint32_t)__popcll(__ballot(did != 0));
         if (lane == 0 && did) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE], (unsigned long long)did);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything bench.py's roofline block and DESIGN.md quote, collected in one go on the GPU box:
+# Everything bench.py's roofline block quotes, collected in one go on the GPU box:
 #   rocprofv3 --kernel-trace --stats of the bench, then the hardware-counter passes (one rocprofv3 --pmc run per pass),
 #   for each workload given.  usage: tools/collect_profiles.sh <tag> [workload ...]   -> gpurun_out/<tag>/
 set -o pipefail
