@@ -40,6 +40,14 @@ def _workloads():
         # light; the second one is this build's: direction (0.6, 0.7, -0.2) normalised, colour 0.6)
         "bunny_lambert_2lights_1080p": (lambda: scenes.bunny(second_light=True),
                                         dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-4, ray_eps=0.1)),
+        # not a BASELINE configuration: the first two with rt_options.skip_unlit - the light rays of hits whose colour the
+        # light cannot change (surfaces facing away from it, no ambient colour) are left out; the frames are the same bit
+        # for bit, fewer rays are traced and counted
+        "bunny_lambert_1080p_skip_unlit": (lambda: scenes.bunny(), dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3,
+                                                                         eps=1e-4, ray_eps=0.1, skip_unlit=1)),
+        "bunny_lambert_2lights_1080p_skip_unlit": (lambda: scenes.bunny(second_light=True),
+                                                   dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-4,
+                                                        ray_eps=0.1, skip_unlit=1)),
         # configs[1]: ground and dome Phong-reflective, 2 bounces (README.md:42-56)
         "bunny_phong_1080p": (lambda: scenes.bunny(phong_surroundings=True),
                               dict(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, ray_eps=0.1)),
@@ -57,7 +65,7 @@ def _workloads():
 
 WORKLOADS = _workloads()
 WORKLOAD_NAMES = ["bunny_lambert_1080p", "bunny_lambert_2lights_1080p", "bunny_phong_1080p", "mirror_room", "glass_balls",
-                  "bunny_field_4k"]
+                  "bunny_field_4k", "bunny_lambert_1080p_skip_unlit", "bunny_lambert_2lights_1080p_skip_unlit"]
 
 
 def kernel_source_sha():

@@ -118,6 +118,15 @@ typedef struct rt_options {
                                    ((l / row_band) * N + row_phase) * row_band + l % row_band  (multi-GPU row bands) */
     int32_t row_band;           /* band height of the interleave (>= 1 when row_stride > 1) */
     int32_t row_phase;          /* which share, 0 .. row_stride-1 */
+    int32_t skip_unlit;         /* 1: in a scene none of whose materials spawns rays, the light rays of a hit are not traced
+                                   toward a light that cannot change its colour whatever they find: a default-material hit
+                                   (src/materials.cpp:4-8 ignores the shadow record) or a Lambert hit whose shaded term
+                                   base * (light * max(0, n.l) + ambient) is zero (src/shaders/basic_shaders.cpp:6-13),
+                                   e.g. a surface facing away from the light with no ambient colour.  The reference traces
+                                   them (src/render_thread.cpp:146-161) and multiplies the zero by what they return; the
+                                   frame is the same bit for bit, rt_stats.rays_any counts only what was traced.
+                                   0: trace every light ray the reference traces.  Ignored in scenes that spawn rays
+                                   (there a later ray of the pixel can read the record these rays leave behind). */
 } rt_options;
 
 typedef struct rt_stats {

@@ -33,12 +33,14 @@ class Options(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("hfov", C.c_float), ("spp", C.c_int32),
                 ("spr", C.c_int32), ("max_bounce", C.c_int32), ("max_refrac_bounce", C.c_int32),
                 ("eps", C.c_float), ("ray_eps", C.c_float), ("jitter_mode", C.c_int32), ("seed", C.c_uint32),
-                ("exact_boxes", C.c_int32), ("count_traversal", C.c_int32), ("row_stride", C.c_int32), ("row_band", C.c_int32), ("row_phase", C.c_int32)]
+                ("exact_boxes", C.c_int32), ("count_traversal", C.c_int32), ("row_stride", C.c_int32), ("row_band", C.c_int32), ("row_phase", C.c_int32),
+                ("skip_unlit", C.c_int32)]
 
     def __init__(self, width=960, height=540, hfov=54.43, spp=2, spr=4, max_bounce=3, max_refrac_bounce=3,
-                 eps=1e-4, ray_eps=0.1, jitter_mode=RT_JITTER_OFF, seed=1, exact_boxes=0, count_traversal=0, row_stride=0, row_band=0, row_phase=0):
+                 eps=1e-4, ray_eps=0.1, jitter_mode=RT_JITTER_OFF, seed=1, exact_boxes=0, count_traversal=0, row_stride=0, row_band=0, row_phase=0,
+                 skip_unlit=0):
         super().__init__(width, height, hfov, spp, spr, max_bounce, max_refrac_bounce, eps, ray_eps,
-                         jitter_mode, seed, exact_boxes, count_traversal, row_stride, row_band, row_phase)
+                         jitter_mode, seed, exact_boxes, count_traversal, row_stride, row_band, row_phase, skip_unlit)
 
 
 class Stats(C.Structure):

@@ -560,6 +560,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     P.eps = o->eps; P.ray_eps = o->ray_eps; P.jitter = o->jitter_mode; P.seed = o->seed;
     P.row_stride = o->row_stride; P.row_band = o->row_band; P.row_phase = o->row_phase;
     P.can_spawn = sc->any_spawning_material ? 1 : 0;
+    P.skip_unlit = (o->skip_unlit != 0 && !sc->any_spawning_material) ? 1 : 0;
     rt::set_divisors(P, sc->n_lights);
     {   // src/render_thread.cpp:34-40 (PI is the float 3.1415926, :3)
         const float aspect_ratio = o->height / (float)o->width;
@@ -618,7 +619,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     const bool timing = stats != nullptr;
     float ms_extend = 0, ms_shadow = 0, ms_shade = 0, ms_total = 0;
     if (timing) HIP_TRY(hipEventRecord(sc->ev[4], s));
-    uint64_t rays_closest = 0, rays_any = 0;
+    uint64_t rays_closest = 0, rays_any = 0, rays_idle = 0;   // idle: light rays rt_options.skip_unlit left out
     int max_levels = 0;
     // light rays traced: only counted when the caller asked for statistics (the count costs an atomic per wave)
     unsigned long long* d_traced = timing ? (unsigned long long*)(d_counters + 16) : nullptr;
@@ -675,6 +676,8 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                 for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) {
                     unsigned long long v; memcpy(&v, sc->h_counters + 16 + q * rt::RT_TRACED_STRIDE * 2, 8);
                     rays_any += v;
+                    memcpy(&v, sc->h_counters + 16 + q * rt::RT_TRACED_STRIDE * 2 + 4, 8);
+                    rays_idle += v;
                 }
             for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); work[q] += v; }
             int64_t kids = 0;
@@ -715,7 +718,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         HIP_TRY(hipEventSynchronize(sc->ev[5]));
         HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev[4], sc->ev[5]));
         stats->rays_closest = rays_closest; stats->rays_any = rays_any;
-        stats->ref_get_hit_calls = 2 * rays_closest + rays_any;
+        stats->ref_get_hit_calls = 2 * rays_closest + rays_any + rays_idle;
         stats->ms_total = ms_total; stats->ms_extend = ms_extend; stats->ms_shadow = ms_shadow; stats->ms_shade = ms_shade;
         stats->levels = max_levels;
         stats->nodes_extend = work[0]; stats->tris_extend = work[1]; stats->nodes_shadow = work[2]; stats->tris_shadow = work[3];

@@ -87,6 +87,7 @@ struct RenderParams {
     int32_t row_stride, row_band, row_phase;   // interleaved row shares (row_stride <= 1: rows are image rows)
     int32_t band_y0, band_rows;                // the band of rows being rendered: first (local) row and height
     int32_t can_spawn;                         // some material of the scene spawns rays (Phong / refractive)
+    int32_t skip_unlit;                        // rt_options.skip_unlit, and the scene spawns no rays
     FastDiv div_spp, div_spp2, div_tiles_x, div_lights, div_rays;   // by spp, spp^2, 4x4 tiles per row, lights, spr + 1
 };
 

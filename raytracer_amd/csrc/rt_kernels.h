@@ -159,6 +159,22 @@ RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
 
 RT_HD int4 mk_i4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
+// Count byte of a (hit, light) pair whose light rays are not traced because nothing they find can change the colour
+// (rt_options.skip_unlit): the replay multiplies a zero by count / (spr + 1), any finite count gives the same bits.
+enum { RT_UNLIT = 254 };
+RT_HD V3 lambert_shade(V3 ca, V3 cr, V3 cl, V3 n, V3 l);
+
+// true when the light cannot change what apply_shade returns for a hit at p with normal n: the default material ignores
+// the shadow record (src/materials.cpp:4-8), a Lambert hit adds lambert_shade(...) * record - zero times anything
+// finite when the term itself is zero.  The term is computed by the function the replay calls, on the same inputs.
+RT_HD bool light_is_idle(const DScene& sc, const RenderParams& P, const Material& M, V3 p, V3 n, uint32_t key, int li) {
+    if (M.kind == 0) return true;
+    if (M.kind != 1) return false;
+    const V3 l = light_dir(sc.lights[li], p, P, key, SITE_SHADE_LIGHT, (uint32_t)li);
+    const V3 c = lambert_shade(v3p(M.ambient), v3p(M.base), v3p(sc.lights[li].color), n, l);
+    return c.x == 0.f && c.y == 0.f && c.z == 0.f;
+}
+
 // returns the number of children this node will spawn
 template <bool EXACT>
 RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t i,
@@ -195,6 +211,12 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
         if (hit) {
             L.hit[i] = hn; L.pos[i] = pk;
             if (kind == 3) L.aux[i] = r_theta;
+            if (P.skip_unlit) {
+                // every pair gets its byte: the light-ray kernel overwrites the zeros with counts and leaves the others
+                const Material& M = sc.mats[mat];
+                for (int li = 0; li < sc.n_lights; ++li)
+                    L.unocc[i * sc.n_lights + li] = light_is_idle(sc, P, M, f4v(pk), f4v(hn), in.key, li) ? (uint8_t)RT_UNLIT : (uint8_t)0;
+            }
         }
     } else {
         NodeRec* R = L.rec + i;
@@ -211,14 +233,16 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
 // ------------------------------------------------------------------------------------------------ shadow
 // Item w = node * n_lights + light: the spr jittered rays and the exact ray toward one light from the hit point of
 // the node's companion shadow ray (src/render_thread.cpp:146-161); unocc[w] = how many of them reached the light.
-struct ShadowItem { V3 p, exact; uint32_t key; int li; };
+struct ShadowItem { V3 p, exact; uint32_t key; int li; bool idle; };   // idle: not traced, see RT_UNLIT
 
 // false: the shadow-type ray missed, nothing is traced and the record stays stale
 RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, int64_t w, ShadowItem& it) {
     const uint32_t i = fdiv((uint32_t)w, P.div_lights);
     it.li = (int)((uint32_t)w - i * (uint32_t)sc.n_lights);
+    it.idle = false;
     const int comp = L.implicit ? (int)i : L.meta[i].w;
     if (res_tri(L, comp) < 0) return false;
+    if (P.skip_unlit && L.unocc[w] == (uint8_t)RT_UNLIT) { it.idle = true; return false; }   // level 0 only: such scenes have no other
     const float4 pk = res_pos(L, comp);
     it.p = f4v(pk);
     it.key = L.implicit ? (uint32_t)RT_F2I(pk.w) : (uint32_t)RT_F2I(L.org[i].w);

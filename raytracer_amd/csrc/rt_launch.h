@@ -11,7 +11,8 @@ struct LevelSet { Level lv[RT_MAX_LEVELS]; };
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
                    unsigned long long* work, hipStream_t s);
 // traced (may be NULL): light rays traced, accumulated in RT_TRACED_SLOTS counters RT_TRACED_STRIDE apart (one
-// address would serialise the per-wave atomics in one L2 channel); the caller sums the slots
+// address would serialise the per-wave atomics in one L2 channel); the caller sums the slots.  The third 64-bit word
+// of each slot counts the light rays left out under rt_options.skip_unlit
 enum { RT_TRACED_SLOTS = 64, RT_TRACED_STRIDE = 16,
        RT_KIDS_WORD0 = 16 + 2 };     // the children counts share the slots' 128-byte lines: u32 word 2 of each
 void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,

@@ -173,6 +173,53 @@ def test_render_parity(oracle_mod, case, jitter, exact):
         assert sb.ref_get_hit_calls == sa.rays_closest + sa.rays_any
 
 
+def _default_and_point_light_scene():
+    """The bunny scene with the rabbit on the default material (its colour ignores the shadow record) under a point
+    light (the shaded light direction is jittered per hit, src/lights.cpp:34-36)."""
+    from raytracer_amd.scene import Light, Material, MAT_DEFAULT
+    sc = scenes.bunny()
+    sc.materials.append(Material(kind=MAT_DEFAULT))
+    for m in sc.meshes:
+        if m.name == "rabbit":
+            m.material = len(sc.materials) - 1
+    sc.lights = [Light(1, np.array([3.0, 6.0, 4.0], np.float32), np.array([1, 0.9, 0.8], np.float32))]
+    return sc
+
+
+@pytest.mark.parametrize("case", ["bunny_lambert", "bunny_2lights", "spp3", "default_and_point_light"])
+@pytest.mark.parametrize("jitter", [RT_JITTER_OFF, RT_JITTER_HASH])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_skipping_idle_light_rays_changes_no_pixel(oracle_mod, case, jitter, exact):
+    """rt_options.skip_unlit leaves out the light rays of hits whose colour the light cannot change (default material,
+    Lambert term zero): the frame must stay the frame the oracle renders WITH those rays, bit for bit; fewer rays are
+    traced, and the count of get_hit calls the reference would make is still reported."""
+    if case == "default_and_point_light":
+        sc, kw = _default_and_point_light_scene(), dict(width=160, height=90, hfov=60, spp=2, spr=3, max_bounce=3)
+    else:
+        make, kw, _ = CASES[case]
+        sc = make()
+    g, o = _pair(sc, oracle_mod)
+    opt = Options(jitter_mode=jitter, seed=5, exact_boxes=exact, **kw)
+    W, H = opt.width, opt.height
+    a, sa = o.render_rect(opt, 0, 0, W, H)
+    full, sf = g.render_rect(opt, 0, 0, W, H)
+    opt.skip_unlit = 1
+    b, sb = g.render_rect(opt, 0, 0, W, H)
+    assert bits_equal(full, b).all()                       # the same frame as with every light ray traced
+    if exact:
+        assert bits_equal(a, b).all()                      # which is the oracle's
+        assert sb.ref_get_hit_calls == sa.rays_closest + sa.rays_any
+    assert sb.rays_closest == sf.rays_closest and sb.rays_any < sf.rays_any
+    assert sb.ref_get_hit_calls == sf.ref_get_hit_calls
+    # the option is ignored where a later ray of the pixel may read the record these rays leave behind
+    g2 = api.TracerScene(scenes.bunny(phong_surroundings=True))
+    o2 = Options(width=64, height=36, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, jitter_mode=jitter, seed=5, exact_boxes=exact)
+    f0, s0 = g2.render_rect(o2, 0, 0, 64, 36)
+    o2.skip_unlit = 1
+    f1, s1 = g2.render_rect(o2, 0, 0, 64, 36)
+    assert bits_equal(f0, f1).all() and s0.rays_any == s1.rays_any
+
+
 def test_rect_and_band_invariance(bunny_scene):
     """A frame rendered as one rectangle, as tiles, and as bands is the same frame; two runs are bit-identical."""
     g = api.TracerScene(scenes.bunny(phong_surroundings=True))
