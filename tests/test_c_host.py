@@ -13,7 +13,7 @@ HOST = os.path.join(ROOT, "examples", "host")
 
 def test_header_is_c99_and_the_example_links(tmp_path):
     src = tmp_path / "hdr.c"
-    src.write_text('#include "%s"\nint main(void) { return sizeof(rt_options) == 64 && sizeof(rt_stats) == 88 ? 0 : 1; }\n'
+    src.write_text('#include "%s"\nint main(void) { return sizeof(rt_options) == 68 && sizeof(rt_stats) == 88 ? 0 : 1; }\n'
                    % os.path.join(ROOT, "include", "rt_amd.h"))
     exe = str(tmp_path / "hdr")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-o", exe, str(src)])

@@ -54,7 +54,7 @@ def test_option_file_keys():
 
 def test_abi_struct_sizes():
     assert ctypes.sizeof(MaterialDesc) == 64 and ctypes.sizeof(LightDesc) == 32 and ctypes.sizeof(CameraDesc) == 64
-    assert ctypes.sizeof(Options) == 64 and ctypes.sizeof(Stats) == 88
+    assert ctypes.sizeof(Options) == 68 and ctypes.sizeof(Stats) == 88
 
 
 def test_library_exports_every_declared_symbol():
