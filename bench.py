@@ -210,11 +210,20 @@ def main(argv=None):
     # an idle period, 0.80 ms from about the twelfth on).  Frames until 40 ms have passed, at most 40 of them.
     spinup = 0
     torch.cuda.synchronize()
-    t_spin = time.perf_counter()
-    while spinup < 40 and (spinup < 2 or time.perf_counter() - t_spin < 0.04):
-        run(2)
+    if world == 1:
+        t_spin = time.perf_counter()
+        while spinup < 40 and (spinup < 2 or time.perf_counter() - t_spin < 0.04):
+            run(2)
+            torch.cuda.synchronize()
+            spinup += 2
+    else:
+        # every rank must run the same number of frames (each one is a collective): decided from the slowest rank's
+        # first frame, not from this rank's clock
+        slowest = torch.tensor([float(st.ms_total)], dtype=torch.float64, device=dev)
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        spinup = 36 if float(slowest.item()) < 5.0 else 2
+        run(spinup)
         torch.cuda.synchronize()
-        spinup += 2
     run(args.warmup)
     if world > 1:
         dist.barrier()
