@@ -7,7 +7,8 @@
 of the kernel sources it was collected on; bench.py ignores it when that is not the hash of the sources it runs.
 Counter values are means over the launches of the plain (non-counting) kernels.  HBM bytes = 2 * 1024 * FETCH_SIZE +
 1024 * WRITE_SIZE: both counters are in KiB and come from separate passes; on gfx950 FETCH_SIZE reports half the bytes
-of wide (16 bytes per lane) reads, so reads are doubled - narrower reads may be over-counted by up to 2x."""
+read, at every load width (measured with tools/ubench/fetch_calib.hip: 16-, 4- and 1-byte loads per lane), so reads are
+doubled."""
 import collections
 import csv
 import glob
