@@ -12,8 +12,6 @@
 #define RT_CLZ(x) __clz(x)
 #define RT_F2I(x) __float_as_int(x)
 #define RT_I2F(x) __int_as_float(x)
-#define RT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#define RT_ATOMIC_INC(p) atomicAdd((p), 1u)
 #define RT_RCP(x) __builtin_amdgcn_rcpf(x)
 #define RT_LDS_PTR __attribute__((address_space(3)))
 #define RT_BLOCK 256      // threads per workgroup of every kernel that traverses (stride of the LDS stack columns)
@@ -140,13 +138,9 @@ RT_HD uint32_t h_fin(uint32_t h) {
     return h;
 }
 enum { SITE_PRIMARY = 1, SITE_SH_LIGHT = 2, SITE_SH_SPLIT = 3, SITE_SHADE_LIGHT = 4, SITE_REFLECT_SPLIT = 5 };
-// the value one rand() call of the reference returns at this call site
-RT_HD int rnd(int jitter, uint32_t seed, uint32_t node, uint32_t site, uint32_t a, uint32_t b) {
-    if (jitter == 0) return 100;
-    return (int)(h_fin(h_mix(h_mix(h_mix(h_mix(seed, node), site), a), b)) >> 1);
-}
-// rand() at call sites (a, b0), (a, b0 + 1), (a, b0 + 2) of one node - the three components of a jitter vector: the
-// same values as three rnd() calls, with the part of the hash they share computed once and one test of the mode.
+// What rand() returns at call sites (a, b0), (a, b0 + 1), (a, b0 + 2) of one node - the three components of a jitter
+// vector.  jitter == 0: every call returns 100, which makes every jitter term of the reference zero; otherwise
+// h_fin(h_mix(h_mix(h_mix(h_mix(seed, node), site), a), b)) >> 1 per call, the part the three share computed once.
 RT_HD void rnd3(int jitter, uint32_t seed, uint32_t node, uint32_t site, uint32_t a, uint32_t b0, int& r0, int& r1, int& r2) {
     if (jitter == 0) { r0 = r1 = r2 = 100; return; }
     const uint32_t pre = h_mix(h_mix(h_mix(seed, node), site), a);

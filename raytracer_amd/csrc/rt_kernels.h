@@ -88,7 +88,6 @@ struct NodeIn {
 
 RT_HD int meta_type(int y) { return y & 0xff; }
 RT_HD int meta_depth(int y) { return (y >> 8) & 0xff; }
-RT_HD int meta_rank(int y) { return (y >> 16) & 0xff; }
 RT_HD int meta_pack(int type, int depth, int rank) { return type | (depth << 8) | (rank << 16); }
 
 RT_HD V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
@@ -269,73 +268,11 @@ RT_HD bool shadow_ray(const DScene& sc, const RenderParams& P, const ShadowItem&
     return !traverse<true, EXACT>(sc, st, it.p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris);
 }
 
-// The whole item in one lane (what the kernel spreads over spr+1 lanes).  Returns the number of rays traced.
-template <bool EXACT>
-RT_HD int body_shadow(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t w,
-                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
-    ShadowItem it;
-    if (!shadow_item(sc, P, L, w, it)) { if (!L.implicit) store_unocc(sc, P, L, w, RT_NO_COMPANION_HIT); return 0; }
-    uint32_t unocc = 0;
-    for (int k = 0; k <= P.spr; ++k) unocc += shadow_ray<EXACT>(sc, P, it, st, k, n_nodes, n_tris) ? 1u : 0u;
-    store_unocc(sc, P, L, w, unocc);
-    return P.spr + 1;
-}
-
 // ------------------------------------------------------------------------------------------------- spawn
-// writes the children of node i into N[base ...]; the caller reserved res_kid_count(L, i) places
-RT_HD void spawn_children(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t base, int64_t i) {
-    const int tri = res_tri(L, i);
-    if (tri < 0) return;
-    const NodeIn in = node_in(sc, P, L, i);
-    const int depth = meta_depth(in.packed);
-    const Material& M = sc.mats[res_material(sc, L, tri)];
-    if (depth <= 0 || (M.kind != 2 && M.kind != 3)) return;
-    const V3 d = in.d;
-    const V3 n = f4v(res_hit(L, i));
-    const uint32_t key = in.key;
-    const float weight = in.weight;
-    const V3 p = f4v(res_pos(L, i));
-    // mirror direction, src/linmath.h:59-65
-    const float pp = 2.f * vdot(d, n);
-    const V3 rd = v3(d.x - pp * n.x, d.y - pp * n.y, d.z - pp * n.z);
-    if (M.kind == 2) {                                              // src/render_thread.cpp:239-280
-        const int cnt = P.spr + 1;
-        for (int k = 0; k < cnt; ++k) {
-            const V3 dk = (k < P.spr) ? split_dir(rd, P.ray_eps, P, key, SITE_REFLECT_SPLIT, 0, (uint32_t)k) : rd;
-            const uint32_t ck = node_child(key, (uint32_t)k);
-            N.org[base + k] = mk4(p, RT_I2F((int)ck));
-            N.dir[base + k] = mk4(dk, weight);
-            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = in.refraci; cm.w = (int)(base + P.spr);
-            N.meta[base + k] = cm;
-        }
-        set_kids(L, i, (int32_t)base, cnt);
-    } else {                                                        // src/render_thread.cpp:318-394
-        const float refraci = RT_I2F(in.refraci);
-        V3 td = v3(0, 0, 0);
-        const float r_theta = refract_dir(d, n, refraci, M.refractivity, td);
-        const bool both = !(r_theta <= 0);
-        const int cnt = both ? 2 : 1;
-        const int d_rf = (refraci == 1) ? P.D : depth - 1;
-        const int d_rt = (refraci == 1) ? P.Dr : depth - 1;
-        const int zi = RT_F2I(M.refractivity);
-        {
-            N.org[base] = mk4(p, RT_I2F((int)node_child(key, 0)));
-            N.dir[base] = mk4(rd, both ? r_theta * weight : weight);
-            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFRACTIVE, d_rf, 0); cm.z = zi; cm.w = (int)base;
-            N.meta[base] = cm;
-        }
-        if (both) {
-            N.org[base + 1] = mk4(p, RT_I2F((int)node_child(key, 1)));
-            N.dir[base + 1] = mk4(td, (1 - r_theta) * weight);
-            int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFRACTIVE, d_rt, 1); cm.z = zi; cm.w = (int)(base + 1);
-            N.meta[base + 1] = cm;
-        }
-        set_kids(L, i, (int32_t)base, cnt);
-    }
-}
-
-// Child k of node i alone, written to N[at] (the kernel gives every CHILD a lane, so that consecutive lanes write
-// consecutive records; the values are those of spawn_children).  first = place of the node's first child.
+// Child k of node i, written to N[at]: the kernel gives every CHILD a lane, so that consecutive lanes write consecutive
+// records.  first = place of the node's first child (the caller reserved res_kid_count(L, i) places from there).
+// Reflective hit: spr jittered copies of the mirror direction and the mirror direction itself, whose node (first + spr)
+// is the companion of all of them; refractive hit: the reflected ray and, unless reflection is total, the refracted one.
 RT_HD void spawn_child(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t first, uint32_t at, int64_t i, int k) {
     const int tri = res_tri(L, i);
     const NodeIn in = node_in(sc, P, L, i);
@@ -370,12 +307,6 @@ RT_HD void spawn_child(const DScene& sc, const RenderParams& P, const Level& L, 
         }
         N.meta[at] = cm;
     }
-}
-
-// one node at a time (the kernel reserves the places of a whole wave with one atomic instead)
-RT_HD void body_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, uint32_t* next_count, int64_t i) {
-    const int cnt = (P.can_spawn && res_tri(L, i) >= 0) ? res_kid_count(L, i) : 0;
-    if (cnt > 0) spawn_children(sc, P, L, N, RT_ATOMIC_ADD(next_count, (uint32_t)cnt), i);
 }
 
 // ------------------------------------------------------------------------------------------------ replay
