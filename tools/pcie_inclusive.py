@@ -26,6 +26,7 @@ def main():
     d_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     h_rgb = np.empty((H, W, 3), np.float32)
     h_u8 = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
+    h_pin = torch.empty((H, W, 3), dtype=torch.float32).pin_memory().numpy()
 
     def in_hbm():
         tr.render_rect(opt, 0, 0, W, H, out=d_rgb, stats=False, stream=stream)
@@ -34,12 +35,16 @@ def main():
     def floats_to_host():
         tr.render_rect(opt, 0, 0, W, H, out=h_rgb, stats=False, stream=stream)
 
+    def floats_to_pinned():
+        tr.render_rect(opt, 0, 0, W, H, out=h_pin, stats=False, stream=stream)
+
     def bytes_to_host():
         in_hbm()
         h_u8.copy_(d_u8, non_blocking=True)
 
     for name, fn in (("framebuffer and 8-bit image left in HBM (what the bench times)", in_hbm),
                      ("float framebuffer returned in pageable host memory", floats_to_host),
+                     ("float framebuffer returned in pinned host memory", floats_to_pinned),
                      ("8-bit image copied to pinned host memory", bytes_to_host)):
         for _ in range(40):
             fn()
