@@ -384,6 +384,8 @@ def roofline(tracer, opt, W, H, dev, stream, workload):
            "lane_utilisation": util,
            "useful_lane_frac": round(achieved / peak * util, 4) if (achieved and util) else None,
            "valu_insts_per_launch": insts, "salu_insts_per_launch": salu,
+           "l1_data_path_busy_frac": k.get("td_busy_frac"), "l1_address_path_busy_frac": k.get("ta_busy_frac"),
+           "l1_accesses_per_launch": k.get("l1_accesses"),
            "hbm_frac_measured": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
            "hbm_traffic_over_algorithmic_queue_bytes": round(traffic / max(b - 64 * nn - 48 * nt, 1), 3) if traffic else None,
            "algorithmic_bytes_per_launch": int(b), "algorithmic_GBps_cache_served": round(b / (ms * 1e-3) / 1e9, 1),
@@ -391,7 +393,8 @@ def roofline(tracer, opt, W, H, dev, stream, workload):
            "ms_extend": round(ms_ext, 4), "ms_shadow": round(ms_sha, 4), "ms_replay": round(ms_shade, 4),
            "kernel_src_sha": sha_now, "counters_stale": stale,
            "note": "valu_issue: SQ_INSTS_VALU of the kernel (profiles/traffic.json, collected on the sources kernel_src_sha names) "
-                   "over its launch time, against 1 wave instruction per SIMD per 2 cycles on 1024 SIMDs at 2.4 GHz; traffic = HBM "
+                   "over its launch time, against 1 wave instruction per SIMD per 2 cycles on 1024 SIMDs at 2.4 GHz; l1_*_busy_frac = "
+                   "TD_TD_BUSY / TA_TA_BUSY over SQ_BUSY_CU_CYCLES (the CUs' vector-memory return and address paths); traffic = HBM "
                    "bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (reads doubled, gfx950); the tree is cache "
                    "resident, so algorithmic node/triangle bytes are not HBM traffic"}
     return out

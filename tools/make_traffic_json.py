@@ -84,6 +84,12 @@ def main():
                 e["l1_hit_rate_est"] = round(1 - v["TCP_TCC_READ_REQ_sum"] / v["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
             if "TCC_HIT_sum" in v and v["TCC_HIT_sum"] + v.get("TCC_MISS_sum", 0) > 0:
                 e["l2_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
+            if v.get("TD_TD_BUSY_sum") and v.get("SQ_BUSY_CU_CYCLES"):
+                e["td_busy_frac"] = round(v["TD_TD_BUSY_sum"] / v["SQ_BUSY_CU_CYCLES"], 3)     # L1 data-return path busy
+            if v.get("TA_TA_BUSY_sum") and v.get("SQ_BUSY_CU_CYCLES"):
+                e["ta_busy_frac"] = round(v["TA_TA_BUSY_sum"] / v["SQ_BUSY_CU_CYCLES"], 3)     # L1 address path busy
+            if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                e["l1_accesses"] = int(v["TCP_TOTAL_CACHE_ACCESSES_sum"])
             if k in d:
                 e["rocprof_avg_ms"] = d[k]
             wdoc[k] = e
