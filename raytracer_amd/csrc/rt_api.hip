@@ -292,6 +292,8 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
         return rc;
     } else { sc->fast_nodes = (int64_t)fast.nodes.size(); sc->fast_depth = fast.max_depth; }
     sc->built_on_device = on_device;
+    rt::launch_pack_refs(const_cast<rt::Node64*>(sc->d_fast.nodes), sc->fast_nodes, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "packing the tree's references failed"); }
     const rt::DScene fast_ptrs = sc->d_fast;
     sc->d.n_lights = n_lights;
     for (int i = 0; i < n_lights; ++i) {
@@ -324,7 +326,11 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
 // Invariants of a flattened tree (which != 0: the refined reference pair and run lengths): every triangle in exactly one
 // leaf, every child box holds its subtree's vertices and its children's boxes, child references in range, tie ranks a
 // permutation, depth within the traversal stack.  out as documented for rt_tree_check.
-static int verify_tree(const rt::FlatScene& f, int which, const rt_mesh_desc* meshes, int n_meshes, int64_t out[8]) {
+// packed: the tree as a scene holds it on the device - its planes carry reference bytes (rt_device.h packed_ref) and have
+// each moved outwards by up to 511 units in the last place on their own, so a child's box may stick out of its parent's by
+// that much; the packed references must equal the stored ones.
+static uint32_t float_key(float f) { uint32_t b; memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+static int verify_tree(const rt::FlatScene& f, int which, const rt_mesh_desc* meshes, int n_meshes, int64_t out[8], bool packed = false) {
     const int64_t nt = (int64_t)f.tris.size(), nn = (int64_t)f.nodes.size();
     if ((int64_t)f.info.size() != nt || (int64_t)f.nrm.size() != nt * 9) return fail(RT_ERR_INVALID, "tree check: array sizes differ");
     // original vertices by global triangle id
@@ -359,8 +365,15 @@ static int verify_tree(const rt::FlatScene& f, int which, const rt_mesh_desc* me
             for (int s = 0; s < 2; ++s) {
                 if (r2[s] == rt::RT_NONE) continue;
                 const float* b = s ? c.rbox : c.lbox;
+                const int64_t slack = packed ? 1024 : 0;          // in units in the last place
                 for (int i = 0; i < 3; ++i)
-                    if (b[i] < it.box[i] || b[3 + i] > it.box[3 + i]) return fail(RT_ERR_INVALID, "tree check: a child box sticks out of its parent's");
+                    if ((int64_t)float_key(b[i]) + slack < (int64_t)float_key(it.box[i]) || (int64_t)float_key(b[3 + i]) > (int64_t)float_key(it.box[3 + i]) + slack)
+                        return fail(RT_ERR_INVALID, "tree check: a child box sticks out of its parent's");
+                if (packed) {
+                    uint32_t ref = 0;
+                    for (int k = 0; k < 4; ++k) { uint32_t w; memcpy(&w, &b[k], 4); ref |= (w & 0xffu) << (8 * k); }
+                    if ((int32_t)ref != r2[s]) return fail(RT_ERR_INVALID, "tree check: a reference packed into the box planes differs from the stored one");
+                }
             }
             if (!push_children(it.ref, it.depth)) return fail(RT_ERR_INVALID, "tree check: node reached twice or out of range");
             continue;
@@ -438,7 +451,7 @@ int rt_scene_check_tree(rt_scene* sc, const rt_mesh_desc* meshes, int n_meshes, 
     HIP_TRY(hipMemcpy(f.tris.data(), sc->d_fast.tris, f.tris.size() * sizeof(rt::Tri48), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(f.info.data(), sc->d_fast.info, f.info.size() * sizeof(rt::TriInfo), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(f.nrm.data(), sc->d_fast.nrm, f.nrm.size() * sizeof(float), hipMemcpyDeviceToHost));
-    const int rc = verify_tree(f, 1, meshes, n_meshes, out);
+    const int rc = verify_tree(f, 1, meshes, n_meshes, out, /*packed*/ true);
     if (rc != RT_OK) return rc;
     if (out[3] != sc->fast_depth) return fail(RT_ERR_INVALID, "tree check: the recorded depth differs from the tree's");
     out[7] = sc->built_on_device ? 1 : 0;

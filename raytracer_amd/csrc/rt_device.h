@@ -35,12 +35,32 @@ typedef float rt_f16 __attribute__((ext_vector_type(16)));
                                    rd, lo, lim);                                                             \
         } else {                                                                                             \
             const float4* np_ = reinterpret_cast<const float4*>((nodes) + (cur));                            \
-            const float4 q0 = np_[0], q1 = np_[1], q2 = np_[2], q3 = np_[3];                                 \
-            RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2); RT_KEEP4(q3);                                          \
-            cur = node_step<EXACT, OCT, ORDER>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, \
-                                   RT_F2I(q3.x), RT_F2I(q3.y), RT_F2I(q3.z), RT_F2I(q3.w), st, o, d, rd, lo, lim); \
+            const float4 q0 = np_[0], q1 = np_[1], q2 = np_[2];                                              \
+            RT_KEEP4(q0); RT_KEEP4(q1); RT_KEEP4(q2);                                                        \
+            if (EXACT) {                                                                                     \
+                const float4 q3 = np_[3];                                                                    \
+                RT_KEEP4(q3);                                                                                \
+                cur = node_step<EXACT, OCT, ORDER>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, \
+                                       RT_F2I(q3.x), RT_F2I(q3.y), RT_F2I(q3.z), RT_F2I(q3.w), st, o, d, rd, lo, lim); \
+            } else {                                                                                         \
+                /* the pruning traversal's tree carries its two references in the low bytes of eight box planes */ \
+                const int32_t rl_ = packed_ref(q0.x, q0.y, q0.z, q0.w), rr_ = packed_ref(q1.z, q1.w, q2.x, q2.y); \
+                cur = node_step<EXACT, OCT, ORDER>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, \
+                                       rl_, rr_, rl_, rr_, st, o, d, rd, lo, lim);                            \
+            }                                                                                                \
         }                                                                                                    \
     } while (0)
+
+// The pruning traversal's nodes carry their two child references a second time, byte by byte in the lowest mantissa
+// byte of eight of the twelve box planes (rt_api.hip packs them when a scene is created, moving each plane outwards by
+// less than 512 units in the last place so that the box only grows): a lane that fetches its own node then needs 48
+// bytes, three loads, instead of 64 - the vector-memory path is the busiest unit of these kernels.  Byte k of the
+// reference is the low byte of plane k of its box (lo.x, lo.y, lo.z, hi.x).
+__device__ __forceinline__ int32_t packed_ref(float a, float b, float c, float d) {
+    const uint32_t ab = __builtin_amdgcn_perm((uint32_t)__float_as_int(b), (uint32_t)__float_as_int(a), 0x0c0c0400u);
+    const uint32_t cd = __builtin_amdgcn_perm((uint32_t)__float_as_int(d), (uint32_t)__float_as_int(c), 0x0c0c0400u);
+    return (int32_t)__builtin_amdgcn_perm(cd, ab, 0x05040100u);
+}
 
 #ifndef RT_ANY_HIT_NEAR_FIRST
 #define RT_ANY_HIT_NEAR_FIRST 0   // 1: any-hit rays also visit the nearer child first (measured: no faster, and three

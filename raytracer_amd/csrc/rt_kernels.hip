@@ -194,6 +194,32 @@ __global__ __launch_bounds__(BLOCK) void k_resolve_u8(const float* rgb, int W, i
     if (i < n) body_resolve_u8(rgb, W, H, i, out);
 }
 
+// Writes byte k of a child reference into the low mantissa byte of plane k of that child's box (see packed_ref), moving
+// a lower plane down and an upper plane up to the nearest float with that low byte: at most 511 units in the last place,
+// never inwards.  Works on the order-preserving integer image of a float (all bits flipped for negative numbers, the
+// sign bit set for the others), in which a block of 256 consecutive values shares its upper 24 bits and its sign.
+__device__ __forceinline__ uint32_t float_key(float f) { const uint32_t b = (uint32_t)__float_as_int(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float key_float(uint32_t k) { return __int_as_float((int)((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k)); }
+__device__ __forceinline__ float plane_with_byte(float f, uint32_t byte, bool upwards) {
+    if (!(fabsf(f) < 3.0e38f)) f = (f > 0.f) ? 3.0e38f : -3.0e38f;        // planes of an absent child's box
+    const uint32_t k = float_key(f);
+    auto in_block = [&](uint32_t blk) { return (blk << 8) | ((blk & 0x800000u) ? byte : (~byte & 0xffu)); };
+    uint32_t blk = k >> 8, c = in_block(blk);
+    if (upwards ? (c < k) : (c > k)) c = in_block(upwards ? blk + 1u : blk - 1u);
+    return key_float(c);
+}
+__global__ __launch_bounds__(BLOCK) void k_pack_refs(Node64* nodes, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Node64 nd = nodes[i];
+    const uint32_t refs[2] = {(uint32_t)nd.lref_fine, (uint32_t)nd.rref_fine};
+    for (int s = 0; s < 2; ++s) {
+        float* b = s ? nd.rbox : nd.lbox;
+        for (int k = 0; k < 4; ++k) b[k] = plane_with_byte(b[k], (refs[s] >> (8 * k)) & 0xffu, /*upwards*/ k == 3);
+    }
+    nodes[i] = nd;
+}
+
 inline unsigned blocks(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 }  // namespace
@@ -248,6 +274,9 @@ void launch_trace(bool any, bool exact, const DScene& sc, const float* org, cons
     else if (any) k_trace<true, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
     else if (exact) k_trace<false, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
     else k_trace<false, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
+}
+void launch_pack_refs(Node64* nodes, int64_t n, hipStream_t s) {
+    if (n > 0) k_pack_refs<<<blocks(n), BLOCK, 0, s>>>(nodes, n);
 }
 void launch_resolve_u8(const float* rgb, int W, int H, uint8_t* out, hipStream_t s) {
     const int64_t n = (int64_t)W * H * 3;

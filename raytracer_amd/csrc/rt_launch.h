@@ -26,6 +26,8 @@ void launch_replay_flat(const DScene& sc, const RenderParams& P, const LevelSet&
 void launch_shade_sum(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_nodes0, int64_t n_pixels, float* rgb_out, hipStream_t s);
 void launch_trace(bool any, bool exact, const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t n,
                   float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct, hipStream_t s);
+// the pruning traversal's nodes get their child references packed into their box planes (rt_device.h packed_ref)
+void launch_pack_refs(Node64* nodes, int64_t n, hipStream_t s);
 void launch_resolve_u8(const float* rgb, int W, int H, uint8_t* out, hipStream_t s);
 
 }  // namespace rt

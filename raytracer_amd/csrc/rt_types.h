@@ -14,6 +14,9 @@ static const int32_t RT_NONE = INT32_MIN;
 // Two pairs of child references share the boxes: lref/rref describe the reference's tree exactly (its bottom
 // nodes are leaves, however many triangles they hold); lref_fine/rref_fine are the same except that a leaf with
 // more than a few triangles is replaced by a small subtree over that leaf's triangles (appended nodes).
+// In the tree of the pruning traversal, as a scene holds it on the device, the low mantissa byte of lbox[0..3] and of
+// rbox[0..3] spells lref_fine and rref_fine once more (byte k in plane k, planes moved outwards to make room): a lane
+// fetching its own node reads the first 48 bytes only.
 struct alignas(16) Node64 {
     float lbox[6];   // left child: lo.xyz, hi.xyz
     float rbox[6];   // right child
