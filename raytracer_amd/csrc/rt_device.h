@@ -14,7 +14,11 @@
 #define RT_I2F(x) __int_as_float(x)
 #define RT_RCP(x) __builtin_amdgcn_rcpf(x)
 #define RT_LDS_PTR __attribute__((address_space(3)))
-#define RT_BLOCK 256      // threads per workgroup of every kernel that traverses (stride of the LDS stack columns)
+// Threads per workgroup of the kernels (and stride of the LDS stack columns): ONE wave.  A workgroup's LDS is held until
+// its slowest wave is done, and waves of light rays end at very different times; with four waves per workgroup the
+// finished ones' slots stayed empty behind a straggler (64 against 256: bunny frame 1.073 -> 1.047 ms, 10 M-triangle
+// field 1.36 -> 1.27 s; 512 was 12 % slower than 256).
+#define RT_BLOCK 64
 // keeps all four lanes of a loaded float4 "used" so that the load stays one 16-byte instruction
 #define RT_KEEP4(q) asm volatile("" ::"v"((q).x), "v"((q).y), "v"((q).z), "v"((q).w))
 
