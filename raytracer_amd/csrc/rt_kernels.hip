@@ -189,8 +189,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float* org, co
     if (i < n) body_trace<ANY, EXACT>(sc, org, dir, t0, t1, i, t_out, tri_out, nrm_out, cn, ct, st);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_resolve_u8(const float* rgb, int W, int H, int64_t n, uint8_t* out) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+// kernels without a traversal stack or a tail of slow waves keep four waves per workgroup (fewer, fuller workgroups)
+constexpr int FLAT_BLOCK = 256;
+__global__ __launch_bounds__(FLAT_BLOCK) void k_resolve_u8(const float* rgb, int W, int H, int64_t n, uint8_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * FLAT_BLOCK + threadIdx.x;
     if (i < n) body_resolve_u8(rgb, W, H, i, out);
 }
 
@@ -208,8 +210,8 @@ __device__ __forceinline__ float plane_with_byte(float f, uint32_t byte, bool up
     if (upwards ? (c < k) : (c > k)) c = in_block(upwards ? blk + 1u : blk - 1u);
     return key_float(c);
 }
-__global__ __launch_bounds__(BLOCK) void k_pack_refs(Node64* nodes, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+__global__ __launch_bounds__(FLAT_BLOCK) void k_pack_refs(Node64* nodes, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * FLAT_BLOCK + threadIdx.x;
     if (i >= n) return;
     Node64 nd = nodes[i];
     const uint32_t refs[2] = {(uint32_t)nd.lref_fine, (uint32_t)nd.rref_fine};
@@ -276,11 +278,11 @@ void launch_trace(bool any, bool exact, const DScene& sc, const float* org, cons
     else k_trace<false, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
 }
 void launch_pack_refs(Node64* nodes, int64_t n, hipStream_t s) {
-    if (n > 0) k_pack_refs<<<blocks(n), BLOCK, 0, s>>>(nodes, n);
+    if (n > 0) k_pack_refs<<<(unsigned)((n + FLAT_BLOCK - 1) / FLAT_BLOCK), FLAT_BLOCK, 0, s>>>(nodes, n);
 }
 void launch_resolve_u8(const float* rgb, int W, int H, uint8_t* out, hipStream_t s) {
     const int64_t n = (int64_t)W * H * 3;
-    if (n > 0) k_resolve_u8<<<blocks(n), BLOCK, 0, s>>>(rgb, W, H, n, out);
+    if (n > 0) k_resolve_u8<<<(unsigned)((n + FLAT_BLOCK - 1) / FLAT_BLOCK), FLAT_BLOCK, 0, s>>>(rgb, W, H, n, out);
 }
 
 }  // namespace rt
