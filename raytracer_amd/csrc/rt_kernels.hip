@@ -29,6 +29,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
+// Workgroups are handed to the eight XCDs (each with its own L2) in turn: hardware workgroup b runs on XCD b % 8.  With
+// one wave per workgroup, eight consecutive waves - neighbours in the image, which read neighbouring queue records and
+// the same nodes - would land in eight different L2s.  Inside every run of 64 workgroups the kernels therefore swap the
+// two 3-bit digits of b: XCD x takes the 8 CONSECUTIVE work units 8x .. 8x+7 of the run.  (Giving each XCD one
+// contiguous eighth of the whole launch is no good: the parts of an image differ too much in cost - 1.03 -> 1.95 ms;
+// 32 consecutive units per XCD instead of 8 made no difference.)
+// Grids are rounded up to a multiple of 64 (xcd_grid); every kernel already ignores units beyond its data.
+__device__ __forceinline__ uint32_t xcd_block() {
+    const uint32_t b = blockIdx.x;
+    return (b & ~63u) | ((b & 7u) << 3) | ((b >> 3) & 7u);
+}
+
 // work[0] += inner nodes fetched, work[1] += triangles tested (COUNT builds only)
 template <bool COUNT>
 __device__ __forceinline__ void add_work(unsigned long long* work, uint32_t nn, uint32_t nt) {
@@ -40,7 +52,7 @@ __device__ __forceinline__ void add_work(unsigned long long* work, uint32_t nn, 
 
 template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)xcd_block() * BLOCK + threadIdx.x;
     uint32_t kids = 0, nn = 0, nt = 0;
     RT_DECLARE_STACK(st);
     if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
@@ -59,7 +71,7 @@ template <bool EXACT, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, FastDiv div_nodes, uint32_t n_nodes, unsigned long long* traced, unsigned long long* work) {
     const int R = P.spr + 1, per_wave = 64 / R;
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t wave = ((int64_t)xcd_block() * BLOCK + threadIdx.x) >> 6;
     const int sub = (int)fdiv((uint32_t)lane, P.div_rays), k = lane - sub * R;
     // items are taken light by light (all nodes toward light 0, then light 1, ...): the rays of a wave then go toward
     // the same light and share a direction octant; item number w = node * n_lights + light is what the records use
@@ -148,7 +160,7 @@ struct EmitOne {
 __global__ __launch_bounds__(BLOCK) void k_replay_flat(DScene sc, RenderParams P, LevelSet ls, int64_t n_slots, float* rgb_out) {
     const int spp2 = P.spp * P.spp, per_wave = 64 / spp2;
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t wave = ((int64_t)xcd_block() * BLOCK + threadIdx.x) >> 6;
     const int sub = (int)fdiv((uint32_t)lane, P.div_spp2), smp = lane - sub * spp2;
     const int64_t slot = wave * per_wave + sub;
     const bool active = sub < per_wave && slot < n_slots;
@@ -223,13 +235,14 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_pack_refs(Node64* nodes, int64_t
 }
 
 inline unsigned blocks(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+inline unsigned xcd_grid(int64_t n) { return (blocks(n) + 63u) & ~63u; }      // for the kernels that use xcd_block()
 
 }  // namespace
 
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
                    unsigned long long* work, hipStream_t s) {
     if (n <= 0) return;
-    const unsigned g = blocks(n);
+    const unsigned g = xcd_grid(n);
     if (work) {
         if (exact) k_extend<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
         else k_extend<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
@@ -242,7 +255,7 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
                    unsigned long long* work, hipStream_t s) {
     if (n_items <= 0) return;
     const int64_t per_wave = 64 / (P.spr + 1);
-    const unsigned g = blocks((n_items + per_wave - 1) / per_wave * 64);
+    const unsigned g = xcd_grid((n_items + per_wave - 1) / per_wave * 64);
     const uint32_t n_nodes = (uint32_t)(n_items / std::max(sc.n_lights, 1));
     const FastDiv dn = make_fastdiv(n_nodes);
     if (work) {
@@ -262,7 +275,7 @@ void launch_replay(const DScene& sc, const RenderParams& P, const LevelSet& ls, 
 void launch_replay_flat(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_slots, float* rgb_out, hipStream_t s) {
     if (n_slots <= 0) return;
     const int64_t per_wave = 64 / (P.spp * P.spp);
-    k_replay_flat<<<blocks((n_slots + per_wave - 1) / per_wave * 64), BLOCK, 0, s>>>(sc, P, ls, n_slots, rgb_out);
+    k_replay_flat<<<xcd_grid((n_slots + per_wave - 1) / per_wave * 64), BLOCK, 0, s>>>(sc, P, ls, n_slots, rgb_out);
 }
 void launch_shade_sum(const DScene& sc, const RenderParams& P, const LevelSet& ls, int64_t n_nodes0, int64_t n_pixels, float* rgb_out, hipStream_t s) {
     if (n_nodes0 > 0) k_shade<<<blocks(n_nodes0), BLOCK, 0, s>>>(sc, P, ls, n_nodes0);
