@@ -1,7 +1,7 @@
 """Lane utilisation of the traversal loops: runs one counted frame with the normal library (steps per lane) and one with
 a build made with -DRT_COUNT_WAVE_STEPS (steps per wave), and prints  lane steps / (64 * wave steps)  per loop.
 build the second library first:
-  cd raytracer_amd/csrc && hipcc <Makefile flags> -DRT_COUNT_WAVE_STEPS -shared -o ../../tools/librt_wave.so rt_api.hip rt_kernels.hip bvh_build.cpp
+  cd raytracer_amd/csrc && hipcc <Makefile flags> -DRT_COUNT_WAVE_STEPS -shared -pthread -o ../../tools/librt_wave.so <the Makefile's SRC>
 usage: python tools/wave_util.py [workload]   (runs itself once per library, in child processes)"""
 import json
 import os
