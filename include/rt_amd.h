@@ -175,7 +175,10 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes,
 int rt_scene_destroy(rt_scene* scene);
 
 /* Downloads the tree the pruning traversal of `scene` walks and verifies it on the host like rt_tree_check (meshes: the
- * arrays the scene was created from).  out as for rt_tree_check; out[7] = 1 when the tree was built on the device. */
+ * arrays the scene was created from).  out as for rt_tree_check; out[7] = 1 when the tree was built on the device.
+ * The device copy carries each node's child references a second time in the low mantissa bytes of its box planes (the
+ * planes moved outwards by less than 512 units in the last place to make room): the check also verifies those bytes and
+ * lets a child's box stick out of its parent's by that much. */
 int rt_scene_check_tree(rt_scene* scene, const rt_mesh_desc* meshes, int n_meshes, int64_t out[8]);
 
 /* Shape of the flattened tree: counts[0]=triangles, [1]=inner nodes, [2]=leaves, [3]=max depth. */
