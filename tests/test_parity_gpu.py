@@ -220,6 +220,39 @@ def test_skipping_idle_light_rays_changes_no_pixel(oracle_mod, case, jitter, exa
     assert bits_equal(f0, f1).all() and s0.rays_any == s1.rays_any
 
 
+def test_option_and_scene_limits(oracle_mod):
+    """The largest values the boundary accepts - 8 lights (directional and point), -spr 15 (16 light rays per hit and
+    light, 16 children per reflective hit), -spp 16 (256 samples per pixel) - against the oracle, and the status codes
+    one step beyond them."""
+    from raytracer_amd.scene import Light
+    rng = np.random.RandomState(3)
+    sc = scenes.bunny(phong_surroundings=True)
+    sc.lights = []
+    for k in range(8):
+        v = rng.normal(size=3).astype(np.float32)
+        v[1] = abs(v[1]) + 0.3
+        if k % 2 == 0:
+            sc.lights.append(Light(0, (v / np.linalg.norm(v)).astype(np.float32), np.full(3, 0.2, np.float32)))
+        else:
+            sc.lights.append(Light(1, (4 * v).astype(np.float32), np.full(3, 0.2, np.float32)))
+    g, o = _pair(sc, oracle_mod)
+    for kw in (dict(width=24, height=16, spp=2, spr=15, max_bounce=1), dict(width=6, height=4, spp=16, spr=1, max_bounce=1)):
+        opt = Options(hfov=60, eps=1e-3, jitter_mode=RT_JITTER_HASH, seed=2, exact_boxes=1, **kw)
+        a, sa = o.render_rect(opt, 0, 0, opt.width, opt.height)
+        b, sb = g.render_rect(opt, 0, 0, opt.width, opt.height)
+        assert bits_equal(a, b).all()
+        assert sb.ref_get_hit_calls == sa.rays_closest + sa.rays_any
+    opt = Options(width=8, height=8, spp=2, spr=16)
+    with pytest.raises(api.RtError):
+        g.render_rect(opt, 0, 0, 8, 8)
+    opt = Options(width=8, height=8, spp=17, spr=1)
+    with pytest.raises(api.RtError):
+        g.render_rect(opt, 0, 0, 8, 8)
+    sc.lights.append(sc.lights[0])
+    with pytest.raises(api.RtError):
+        api.TracerScene(sc)
+
+
 def test_rect_and_band_invariance(bunny_scene):
     """A frame rendered as one rectangle, as tiles, and as bands is the same frame; two runs are bit-identical."""
     g = api.TracerScene(scenes.bunny(phong_surroundings=True))
