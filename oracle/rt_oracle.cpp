@@ -4,10 +4,12 @@
 // from the algorithm, float32 throughout, same operation order, no FMA contraction (build with
 // -ffp-contract=off).  Every function cites the reference lines it follows.
 //
-// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path, and its
-// own sources cannot be built in this image (every translation unit includes Assimp headers that
-// need a CMake-generated config.h), so this restatement has not been checked against outputs of
-// the reference itself.  It is checked against analytic known answers (tests/test_oracle.py).
+// WHAT PINS IT: the reference's sources cannot be built or run here, and it ships no tests or golden vectors for
+// this path.  What it does ship are two of its own 1920x1080 result images and figures recorded from its runs; this
+// restatement is checked against those (tests/test_reference_images.py, tests/test_oracle.py: silhouette, horizon,
+// shadow side and hit counts) and against analytic known answers.  That pins geometry, camera and light conventions
+// and the ray bookkeeping; the last bits of a colour are NOT pinned by anything the reference holds ("parity
+// unpinned" at the bit level).
 //
 // Defined where the reference is undefined (uninitialised reads):
 //   * reflect children inherit the parent's weight and refraci (src/render_thread.cpp:240-262 never set
@@ -17,7 +19,11 @@
 //   * a TriangleSet's box is the union of its triangles' boxes (src/geometry.cpp:413-417 starts the
 //     union from an uninitialised box); a depth-capped node gets that box too (src/geometry.cpp:65-69
 //     leaves it unset);
-//   * the per-pixel shadow record starts as 1.0 per light (src/render_thread.cpp:115 starts empty).
+//   * the per-pixel shadow record starts as 1.0 per light (src/render_thread.cpp:115 starts empty);
+//   * a get_hit that returns true without having filled the record - every t a mesh reported was +inf (ray parallel
+//     to a triangle through one of its edges) or NaN (zero-area triangle, ray with a NaN direction) - leaves the caller
+//     with a hitrec nobody wrote (src/render_thread.cpp:121): here its mesh matches none, so a render ray draws
+//     nothing, and its shadow twin's light rays start at a non-finite point.  PixelStats::unset counts these.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -350,7 +356,10 @@ float refract(const RayG& in, const vec3 norm, float n, float nt, float t, RayG&
     return r_theta;
 }
 
-struct PixelStats { uint64_t closest = 0, any = 0; };
+// unset: get_hit calls of the bounce loop that returned true without ever filling the record (every reported t was
+// +inf or NaN): the reference then reads a hitrec it never wrote (src/render_thread.cpp:121,141,180), so its result
+// for such a pixel is not defined and nothing here can pin it
+struct PixelStats { uint64_t closest = 0, any = 0, unset = 0; };
 
 // src/render_thread.cpp:43-485 for ONE pixel (i = column, j = row counted from the bottom)
 void render_pixel(const orc_scene& sc, const rt_options& o, int i, int j, float out_rgb[3], PixelStats& st) {
@@ -395,6 +404,7 @@ void render_pixel(const orc_scene& sc, const rt_options& o, int i, int j, float 
         Hit rec;
         bool hit = get_hit(sc, ray.g, o.eps, INFINITY, rec);
         st.closest++;
+        if (hit && rec.mesh < 0) st.unset++;
         vec3 c = {0, 0, 0};
         bool draw = false;
         if (hit) {
@@ -605,7 +615,7 @@ int orc_render_rect(const orc_scene* sc, const rt_options* o, int x0, int y0, in
     for (int i = x0; i < x1; ++i)
         for (int j = y0; j < y1; ++j)
             render_pixel(*sc, *o, i, j, rgb_out + ((size_t)(j - y0) * w + (i - x0)) * 3, st);
-    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_closest = st.closest; stats->rays_any = st.any; stats->ref_get_hit_calls = st.closest + st.any; }
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_closest = st.closest; stats->rays_any = st.any; stats->ref_get_hit_calls = st.closest + st.any; stats->reserved_[0] = (int32_t)std::min<uint64_t>(st.unset, 0x7fffffff); }
     return RT_OK;
 }
 
@@ -615,7 +625,7 @@ int orc_render_rect(const orc_scene* sc, const rt_options* o, int x0, int y0, in
 double orc_render_frame_mt(const orc_scene* sc, const rt_options* o, int hw_threads, int prog_disp_span, float* rgb_out, rt_stats* stats) {
     const int thread_n = (int)ceilf(fast_sqrt_bits((float)hw_threads));             // main.cpp:109
     const int W = o->width, H = o->height;
-    std::atomic<uint64_t> n_closest(0), n_any(0);
+    std::atomic<uint64_t> n_closest(0), n_any(0), n_unset(0);
     auto t_start = std::chrono::high_resolution_clock::now();
     for (int i = 0; i < W; i += prog_disp_span)
         for (int j = 0; j < H; j += prog_disp_span) {
@@ -630,18 +640,18 @@ double orc_render_frame_mt(const orc_scene* sc, const rt_options* o, int hw_thre
                     int cbi = sx + block_len, ci = i + img_w, cbj = sy + block_len, cj = j + img_h;
                     const int ex = sx + block_len - cbi / ci * (cbi % ci);
                     const int ey = sy + block_len - cbj / cj * (cbj % cj);
-                    ths.emplace_back([=, &n_closest, &n_any]() {
+                    ths.emplace_back([=, &n_closest, &n_any, &n_unset]() {
                         PixelStats st;
                         for (int x = sx; x < ex; ++x)
                             for (int y = sy; y < ey; ++y)
                                 render_pixel(*sc, *o, x, y, rgb_out + ((size_t)y * W + x) * 3, st);
-                        n_closest += st.closest; n_any += st.any;
+                        n_closest += st.closest; n_any += st.any; n_unset += st.unset;
                     });
                 }
             for (std::thread& t : ths) t.join();
         }
     auto t_stop = std::chrono::high_resolution_clock::now();
-    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_closest = n_closest; stats->rays_any = n_any; stats->ref_get_hit_calls = n_closest + n_any; }
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_closest = n_closest; stats->rays_any = n_any; stats->ref_get_hit_calls = n_closest + n_any; stats->reserved_[0] = (int32_t)std::min<uint64_t>(n_unset, 0x7fffffff); }
     return std::chrono::duration<double>(t_stop - t_start).count();
 }
 

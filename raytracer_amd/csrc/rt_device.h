@@ -412,7 +412,10 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
 template <bool ANY, bool EXACT, int OCT>
 RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRay& rd, float t0, float t1, HitRec& best,
                         uint32_t* n_nodes, uint32_t* n_tris) {
-    best.t = INFINITY; best.tri = -1; best.rank = INT32_MAX; best.beta = 0.f; best.gamma = 0.f;
+    // the empty record loses no tie: a triangle that passes the test with t = +inf (a ray parallel to it through one
+    // of its edges: 0/0 barycentrics pass every comparison) is not a hit - the reference's get_hit keeps a record only
+    // if its t is BELOW the initial INFINITY (src/render_thread.cpp:8,15)
+    best.t = INFINITY; best.tri = -1; best.rank = INT32_MIN; best.beta = 0.f; best.gamma = 0.f;
     const float lo = entry_limit(t0);
     st.sp = 0;
     int32_t cur = 0;

@@ -1,0 +1,163 @@
+"""Differential run of the HIP path against the CPU oracle over seeded random scenes (tests/fuzz_scenes.py): frames in the
+reference-arithmetic mode must be bit-equal (within 1e-5 where a refractive material is in use: device expf), the
+ray counts equal; the pruning traversal - on the host-built and on the device-built tree - must give the oracle's frame
+but for rays through shared edges and coincident triangles (reported, not judged here), and must never report a farther
+hit than the oracle on a batch of rays (set aside and only noted: a hit of the oracle that lies outside its own needle
+triangle, and rays that graze a triangle at less than 1e-3 - both explained where they are tested).  One line per failing seed, a summary at the end.
+usage: python tools/fuzz_parity.py <first seed> <count>"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def check_seed(seed, api, OracleScene, np):
+    from tests.fuzz_scenes import random_scene, random_options, has_refraction
+    from tests.conftest import bits_equal, random_rays
+    sc = random_scene(seed)
+    problems, notes = [], []
+    o = OracleScene(sc)
+    g = api.TracerScene(sc, device_build=False)
+    gd = api.TracerScene(sc, device_build=True)
+    opt = random_options(seed, 1)
+    W, H = opt.width, opt.height
+    a, sa = o.render_rect(opt, 0, 0, W, H)
+    b, sb = g.render_rect(opt, 0, 0, W, H)
+    refr = has_refraction(sc)
+    frame = []
+    if not (np.isnan(a) == np.isnan(b)).all():
+        frame.append("exact: NaN pattern differs in %d values" % int((np.isnan(a) != np.isnan(b)).sum()))
+    if refr:
+        # The device's expf and glibc's differ in the last place.  Random materials and normals give Fresnel weights
+        # outside [0, 1], a pixel is then a difference of large terms, and that last place grows: moving every expf of
+        # the ORACLE by one unit in the last place moves such pixels by 1e-5 absolute (seeds 955 and 2257).  Beyond the
+        # 1e-5 bar of the well-conditioned test scenes a difference is therefore noted up to 1e-4 and fails above.
+        fin = np.isfinite(a) & np.isfinite(b)
+        if not np.allclose(a[fin], b[fin], rtol=1e-4, atol=1e-4):
+            frame.append("exact: refractive frame beyond 1e-4 (max abs %.3g)" % float(np.abs(a[fin] - b[fin]).max()))
+        elif not np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6):
+            notes.append("exact: refractive frame within 1e-4 but beyond 1e-5 (max abs %.3g)" % float(np.abs(a[fin] - b[fin]).max()))
+    elif not bits_equal(a, b).all():
+        frame.append("exact: %d of %d pixels differ" % (int((~bits_equal(a, b).all(axis=-1)).sum()), W * H))
+    if (sb.rays_any, 2 * sb.rays_closest) != (sa.rays_any, sa.rays_closest) and not refr:
+        frame.append("exact: ray counts %d/%d, oracle %d/%d" % (sb.rays_closest, sb.rays_any, sa.rays_closest // 2, sa.rays_any))
+    if sa.reserved_[0]:
+        # the reference reads hit records it never wrote (a NaN ray, a hit at t = +inf): nothing defines such a pixel,
+        # and a difference in this frame is only noted
+        notes += ["%s - the reference's result is undefined here (%d unset hit records)" % (f, sa.reserved_[0]) for f in frame]
+    else:
+        problems += frame
+    # the same frame whatever way it is asked for: idle light rays skipped, a part of the frame alone, interleaved rows
+    opt.skip_unlit = 1
+    b2, _ = g.render_rect(opt, 0, 0, W, H)
+    opt.skip_unlit = 0
+    if not bits_equal(b, b2).all():
+        problems.append("skip_unlit changes %d pixels" % int((~bits_equal(b, b2).all(axis=-1)).sum()))
+    x0, y0 = W // 3, H // 4
+    part, _ = g.render_rect(opt, x0, y0, W - 1, H - 2)
+    if not bits_equal(b[y0:H - 2, x0:W - 1], part).all():
+        problems.append("a rectangle of the frame differs from the frame")
+    from raytracer_amd.distributed import local_to_image_rows
+    rows = local_to_image_rows(H, 3, 1, 2)
+    if len(rows):
+        opt.row_stride, opt.row_band, opt.row_phase = 3, 2, 1
+        band, _ = g.render_rect(opt, 0, 0, W, len(rows), stats=False)
+        opt.row_stride = opt.row_band = opt.row_phase = 0
+        if not bits_equal(b[rows], band).all():
+            problems.append("interleaved rows differ from the frame")
+    opt.exact_boxes = 0
+    for name, h in (("host tree", g), ("device tree", gd)):
+        c, _ = h.render_rect(opt, 0, 0, W, H)
+        fin = np.isfinite(a) & np.isfinite(c)
+        px = ~(np.isclose(a, c, rtol=1e-5, atol=1e-6) | (np.isnan(a) & np.isnan(c))).all(axis=-1)
+        if px.any() and not sa.reserved_[0]:
+            notes.append("pruning, %s: %d of %d pixels differ" % (name, int(px.sum()), W * H))
+    # a batch of rays: ids, distances, the any-hit answer
+    P = np.concatenate([m.pos.reshape(-1, 3) for m in sc.meshes])
+    c0 = P.mean(0)
+    ext = float(np.abs(P - c0).max()) + 0.1
+    org, d = random_rays(4000, seed, center=c0, spread=3.0 * ext)
+    rng = np.random.RandomState(seed)
+    k = len(org) // 2                                           # half of them exactly at corners of triangles
+    dd = P[rng.randint(len(P), size=k)] - org[-k:]
+    d[-k:] = (dd / np.maximum(np.linalg.norm(dd, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+    to, trio, nro = o.trace(org, d, 1e-4, np.inf)
+    ao, _, _ = o.trace(org, d, 1e-4, 10000.0, any_hit=True)
+    tg, trig, nrg = g.trace(org, d, 1e-4, np.inf, exact_boxes=True)
+    if not ((trig == trio).all() and bits_equal(tg, to).all() and bits_equal(nrg, nro).all()):
+        problems.append("exact trace: %d of %d rays differ" % (int((trig != trio).sum() + (~bits_equal(tg, to)).sum()), len(org)))
+    ag, _, _ = g.trace(org, d, 1e-4, 10000.0, any_hit=True, exact_boxes=True)
+    if not (ag == ao).all():
+        problems.append("exact any-hit: %d rays differ" % int((ag != ao).sum()))
+    t_ref = np.where(trio >= 0, to, np.inf)
+    for name, h in (("host tree", g), ("device tree", gd)):
+        tp, trip, nrp = h.trace(org, d, 1e-4, np.inf, exact_boxes=False)
+        t_gpu = np.where(trip >= 0, tp, np.inf)
+        far = ~(t_gpu <= t_ref * (1 + 1e-5))
+        if far.any():
+            # The reference's Cramer test on a needle (determinant near zero) accepts points far outside the triangle;
+            # which of those a tree lets through depends on its boxes.  Such a "hit" of the oracle is no farther-hit
+            # error of the pruning traversal: tell it by the hit point lying outside the triangle's own box.
+            T = np.concatenate([m.pos for m in sc.meshes]).astype(np.float64)
+            for i in np.nonzero(far)[0]:
+                o64, d64 = org[i].astype(np.float64), d[i].astype(np.float64)
+                p = o64 + float(to[i]) * d64
+                tri = T[trio[i]]
+                slack = 1e-4 * (1.0 + np.abs(p).max())
+                n = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+                graze = abs(np.dot(n, d64)) / max(np.linalg.norm(n) * np.linalg.norm(d64), 1e-300)
+                if ((p < tri.min(0) - slack) | (p > tri.max(0) + slack)).any():
+                    far[i] = False
+                    notes.append("pruning trace, %s: ray %d - the oracle's hit lies outside its needle triangle" % (name, i))
+                elif graze < 1e-3 and t_gpu[i] <= t_ref[i] * (1 + 1e-3):
+                    # a ray almost inside the triangle's plane: the distance itself is only good to 1e-7 / graze, and
+                    # two triangles that share the corner it passes through report distances that far apart
+                    far[i] = False
+                    notes.append("pruning trace, %s: ray %d grazes its triangle (sine %.1e), distances %.8g / %.8g" % (name, i, graze, t_ref[i], t_gpu[i]))
+        if far.any():
+            problems.append("pruning trace, %s: %d rays report a FARTHER hit than the oracle" % (name, int(far.sum())))
+        same = trip == trio
+        if not (bits_equal(tp[same], to[same]).all() and bits_equal(nrp[same], nro[same]).all()):
+            problems.append("pruning trace, %s: same triangle, other distance or normal" % name)
+        if same[:-k].mean() < 0.999:
+            notes.append("pruning trace, %s: %d free rays differ in id" % (name, int((~same[:-k]).sum())))
+        ap, _, _ = h.trace(org, d, 1e-4, 10000.0, any_hit=True, exact_boxes=False)
+        miss = np.isfinite(ao) & ~np.isfinite(ap)
+        if miss.any():
+            problems.append("pruning any-hit, %s: %d rays the oracle finds occluded pass" % (name, int(miss.sum())))
+    info = gd.check_tree()
+    if info["reached_tris"] != sc.n_tris:
+        problems.append("device tree reaches %d of %d triangles" % (info["reached_tris"], sc.n_tris))
+    g.check_tree()
+    for h in (g, gd):
+        h.close()
+    return problems, notes
+
+
+def main():
+    import numpy as np
+    import torch  # noqa: F401  (loads the HIP runtime the library shares)
+    from raytracer_amd import api
+    from oracle.oracle import OracleScene
+    api.init(0)
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    bad = noted = 0
+    t0 = time.perf_counter()
+    for seed in range(first, first + count):
+        problems, notes = check_seed(seed, api, OracleScene, np)
+        for p in problems:
+            print("seed %d: FAIL %s" % (seed, p), flush=True)
+        for n in notes:
+            print("seed %d: note %s" % (seed, n), flush=True)
+        bad += bool(problems)
+        noted += bool(notes)
+        if (seed - first) % 20 == 19:
+            print("... %d seeds, %.0f s" % (seed - first + 1, time.perf_counter() - t0), flush=True)
+    print("%d seeds from %d: %d failed, %d with notes, %.0f s" % (count, first, bad, noted, time.perf_counter() - t0), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
