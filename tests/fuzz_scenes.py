@@ -107,6 +107,28 @@ def random_scene(seed):
     return Scene(meshes, mats, lights, Camera.look(eye.astype(F), up, look.astype(F)))
 
 
+def random_big_scene(seed):
+    """Tens of thousands of triangles in clusters of very different density (deep, lopsided trees: the traversal stack
+    beyond its LDS part, leaves at every depth), a fine height field and a sheet, with the random materials, lights
+    and camera of random_scene."""
+    small = random_scene(seed)
+    rng = np.random.RandomState(seed + 424242)
+    parts = []
+    for _ in range(rng.randint(3, 9)):
+        n = int(10 ** (2 + 2.3 * rng.rand()))
+        centre, spread, size = (rng.rand(1, 1, 3) - 0.5) * 4, 10 ** (-2 + 2 * rng.rand()), 10 ** (-3 + 2 * rng.rand())
+        parts.append(centre + rng.normal(size=(n, 1, 3)) * spread + (rng.rand(n, 3, 3) - 0.5) * size)
+    soup = np.concatenate(parts).astype(F)
+    soup = soup[rng.permutation(len(soup))]
+    cut = len(soup) // 2
+    grid = _grid(rng, rng.randint(40, 120), rng.randint(40, 120), snap=rng.rand() < 0.5)
+    meshes = []
+    for k, pos in enumerate([soup[:cut], soup[cut:], grid, _sheet(rng)]):
+        nrm = _face_normals(pos.astype(np.float64))
+        meshes.append(Mesh("big%d" % k, int(rng.randint(len(small.materials))), pos, nrm))
+    return Scene(meshes, small.materials, small.lights, small.camera)
+
+
 def random_options(seed, exact):
     rng = np.random.RandomState(seed + 77777)
     return Options(width=int(rng.randint(8, 49)), height=int(rng.randint(8, 33)), hfov=float(20 + 80 * rng.rand()),

@@ -590,3 +590,15 @@ def test_random_scenes(oracle_mod, first):
         if problems:
             failed[seed] = problems
     assert not failed
+
+
+def test_big_random_scenes(oracle_mod):
+    """The same checks on scenes of tens of thousands of triangles in clusters of very different density (deep,
+    lopsided trees; tests/fuzz_scenes.py::random_big_scene)."""
+    from tools.fuzz_parity import check_seed
+    failed = {}
+    for seed in (0, 2, 5):
+        problems, _ = check_seed(seed, api, oracle_mod.OracleScene, np, big=True)
+        if problems:
+            failed[seed] = problems
+    assert not failed

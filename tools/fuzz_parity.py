@@ -4,7 +4,7 @@ ray counts equal; the pruning traversal - on the host-built and on the device-bu
 but for rays through shared edges and coincident triangles (reported, not judged here), and must never report a farther
 hit than the oracle on a batch of rays (set aside and only noted: a hit of the oracle that lies outside its own needle
 triangle, and rays that graze a triangle at less than 1e-3 - both explained where they are tested).  One line per failing seed, a summary at the end.
-usage: python tools/fuzz_parity.py <first seed> <count>"""
+usage: python tools/fuzz_parity.py <first seed> <count> [big]      (big: tens of thousands of triangles per scene)"""
 import os
 import sys
 import time
@@ -13,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def check_seed(seed, api, OracleScene, np):
-    from tests.fuzz_scenes import random_scene, random_options, has_refraction
+def check_seed(seed, api, OracleScene, np, big=False):
+    from tests.fuzz_scenes import random_scene, random_big_scene, random_options, has_refraction
     from tests.conftest import bits_equal, random_rays
-    sc = random_scene(seed)
+    sc = random_big_scene(seed) if big else random_scene(seed)
     problems, notes = [], []
     o = OracleScene(sc)
     g = api.TracerScene(sc, device_build=False)
@@ -143,17 +143,18 @@ def main():
     from oracle.oracle import OracleScene
     api.init(0)
     first, count = int(sys.argv[1]), int(sys.argv[2])
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     bad = noted = 0
     t0 = time.perf_counter()
     for seed in range(first, first + count):
-        problems, notes = check_seed(seed, api, OracleScene, np)
+        problems, notes = check_seed(seed, api, OracleScene, np, big)
         for p in problems:
             print("seed %d: FAIL %s" % (seed, p), flush=True)
         for n in notes:
             print("seed %d: note %s" % (seed, n), flush=True)
         bad += bool(problems)
         noted += bool(notes)
-        if (seed - first) % 20 == 19:
+        if (seed - first) % (2 if big else 20) == (1 if big else 19):
             print("... %d seeds, %.0f s" % (seed - first + 1, time.perf_counter() - t0), flush=True)
     print("%d seeds from %d: %d failed, %d with notes, %.0f s" % (count, first, bad, noted, time.perf_counter() - t0), flush=True)
     return 1 if bad else 0
