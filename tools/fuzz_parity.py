@@ -67,6 +67,13 @@ def check_seed(seed, api, OracleScene, np, big=False):
         opt.row_stride = opt.row_band = opt.row_phase = 0
         if not bits_equal(b[rows], band).all():
             problems.append("interleaved rows differ from the frame")
+    if all(m.kind in (0, 1) for m in sc.materials):                          # nothing spawns rays: the entry point that
+        import torch                                                          # allocates nothing takes the scene
+        dev = torch.full((H, W, 3), -5.0, dtype=torch.float32, device="cuda")
+        _, sn = g.render_rect(opt, 0, 0, W, H, out=dev, noalloc=True)
+        torch.cuda.synchronize()
+        if not bits_equal(b, dev.cpu().numpy()).all() or (sn.rays_closest, sn.rays_any) != (sb.rays_closest, sb.rays_any):
+            problems.append("rt_render_rect_noalloc differs from rt_render_rect")
     opt.exact_boxes = 0
     for name, h in (("host tree", g), ("device tree", gd)):
         c, _ = h.render_rect(opt, 0, 0, W, H)
