@@ -427,7 +427,7 @@ void render_pixel(const orc_scene& sc, const rt_options& o, int i, int j, float 
                     shadow_rec[li] = sh_frac;
                 }
             } else if (rec.mesh >= 0) {                                             // :177-410
-                // rec.mesh < 0: a mesh reported a hit whose t is NaN (0/0 on a zero-area triangle), which get_hit
+                // rec.mesh < 0: a mesh reported a hit whose t is NaN or +inf, which get_hit
                 // never copies (:15); the reference then compares an unset mesh name with every mesh (:178-180),
                 // matches none and draws nothing
                 const MeshO& mesh = *sc.meshes[rec.mesh];

@@ -632,7 +632,8 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     const bool timing = stats != nullptr;
     float ms_extend = 0, ms_shadow = 0, ms_shade = 0, ms_total = 0;
     if (timing) HIP_TRY(hipEventRecord(sc->ev[4], s));
-    uint64_t rays_closest = 0, rays_any = 0, rays_idle = 0;   // idle: light rays rt_options.skip_unlit left out
+    uint64_t rays_closest = 0, rays_any = 0, rays_idle = 0;   // idle: light rays the reference traces and this path need not
+                                                              // (rt_options.skip_unlit; companions whose hit has no record)
     int max_levels = 0;
     // light rays traced: only counted when the caller asked for statistics (the count costs an atomic per wave)
     unsigned long long* d_traced = timing ? (unsigned long long*)(d_counters + 16) : nullptr;

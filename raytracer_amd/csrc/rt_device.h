@@ -404,7 +404,8 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
 
 // Nearest hit (ANY == false) or any hit (ANY == true) with t in [t0, t1].
 // Returns true on a hit.  Nearest: best = the candidate minimal in (t, tie rank) order, which is the reference's
-// choice among equal t (ranks: see bvh_build.cpp).  EXACT visits every leaf whose box passes the reference's test, like the
+// choice among equal t (ranks: see bvh_build.cpp); when false, best.tri is -1, or -2 if some triangle passed the test
+// without a finite t (the reference then reports a hit whose record nobody filled).  EXACT visits every leaf whose box passes the reference's test, like the
 // reference's exhaustive recursion (src/geometry.cpp:155-187); otherwise subtrees whose entry distance exceeds the
 // best t so far are skipped and the nearer child is visited first.
 // Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
@@ -446,6 +447,9 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRa
                     best.t = t; best.tri = k; best.rank = RT_F2I(p2.w); best.beta = beta; best.gamma = gamma;
                     found = true;
                 }
+                // passed the test with a t that is +inf or NaN and nothing recorded so far: the reference's get_hit
+                // would answer "hit" and leave its record unset (src/render_thread.cpp:13-19); noted as tri = -2
+                else if (!(t < INFINITY) && best.tri == -1) best.tri = -2;
             }
         }
         if (st.sp == 0) break;

@@ -158,6 +158,10 @@ RT_HD float refract_dir(V3 d, V3 norm, float n, float nt, V3& out) {
 
 RT_HD int4 mk_i4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
+// What a node's triangle field holds when the reference's get_hit returns true with a record it never filled (every t
+// reported to it was +inf or NaN): not a hit for anything here, but not the reference's "hit nothing" branch either.
+enum { RT_UNSET_HIT = -2 };
+
 // Count byte of a (hit, light) pair whose light rays are not traced because nothing they find can change the colour
 // (rt_options.skip_unlit): the replay multiplies a zero by count / (spr + 1), any finite count gives the same bits.
 enum { RT_UNLIT = 254 };
@@ -187,7 +191,11 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     float r_theta = 0.f;
     int kids = 0, flags = in.packed;
     float4 pk = mk4(v3(0, 0, 0), 0.f), hn = mk4(v3(0, 0, 0), INFINITY);
-    int kind = 0, mat = -1;
+    // no hit: -1, or RT_UNSET_HIT where the reference's get_hit says "hit" without a record (see traverse_oct): such a
+    // node draws nothing and has no children, and the light rays the reference sends from its non-finite hit point
+    // are counted, not traced
+    const int none = (!hit && meta_type(in.packed) != RAY_NONE && h.tri == RT_UNSET_HIT) ? RT_UNSET_HIT : -1;
+    int kind = 0, mat = none;
     if (hit) {
         const V3 n = hit_normal(sc, h);
         pk = mk4(point_at(in.o, d, h.t), RT_I2F((int32_t)in.key));
@@ -205,7 +213,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
         }
     }
     if (L.implicit) {
-        L.tri[i] = hit ? h.tri : -1;
+        L.tri[i] = hit ? h.tri : none;
         if (P.can_spawn) { int2 kd; kd.x = -1; kd.y = kids; L.kids[i] = kd; }
         if (hit) {
             L.hit[i] = hn; L.pos[i] = pk;
@@ -232,7 +240,7 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
 // ------------------------------------------------------------------------------------------------ shadow
 // Item w = node * n_lights + light: the spr jittered rays and the exact ray toward one light from the hit point of
 // the node's companion shadow ray (src/render_thread.cpp:146-161); unocc[w] = how many of them reached the light.
-struct ShadowItem { V3 p, exact; uint32_t key; int li; bool idle; };   // idle: not traced, see RT_UNLIT
+struct ShadowItem { V3 p, exact; uint32_t key; int li; bool idle; };   // idle: counted but not traced, see RT_UNLIT, RT_UNSET_HIT
 
 // false: the shadow-type ray missed, nothing is traced and the record stays stale
 RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, int64_t w, ShadowItem& it) {
@@ -240,7 +248,8 @@ RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, 
     it.li = (int)((uint32_t)w - i * (uint32_t)sc.n_lights);
     it.idle = false;
     const int comp = L.implicit ? (int)i : L.meta[i].w;
-    if (res_tri(L, comp) < 0) return false;
+    const int comp_tri = res_tri(L, comp);
+    if (comp_tri < 0) { it.idle = (comp_tri == RT_UNSET_HIT); return false; }
     if (P.skip_unlit && L.unocc[w] == (uint8_t)RT_UNLIT) { it.idle = true; return false; }   // level 0 only: such scenes have no other
     const float4 pk = res_pos(L, comp);
     it.p = f4v(pk);
@@ -461,7 +470,7 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
                 F.c = vmul(cc, c_add); F.contrib = 1.f; F.tpc = 0.f;
                 has_kids = n_kids > 0;
             }
-        } else {                                                             // :414-430
+        } else if (tri == -1) {                                              // :414-430; RT_UNSET_HIT draws nothing (:178-180 match no mesh)
             if ((type == RAY_REFLECT && depth < P.D) || (type == RAY_REFRACTIVE && depth < Dr)) { c = cc; draw = true; }
         }
         if (draw) emit(lvl, i, c, weight);                                   // :434-438

@@ -95,10 +95,9 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     if (traced) {
         did = (uint32_t)__popcll(__ballot(did != 0));
         if (lane == 0 && did) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE], (unsigned long long)did);
-        if (P.skip_unlit) {      // light rays the reference would have traced here (third 64-bit word of the slot)
-            const uint32_t idle = (uint32_t)__popcll(__ballot(it.idle));
-            if (lane == 0 && idle) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE + 2], (unsigned long long)idle);
-        }
+        // light rays the reference would have traced here and this kernel does not (third 64-bit word of the slot)
+        const uint32_t idle = (uint32_t)__popcll(__ballot(it.idle));
+        if (lane == 0 && idle) atomicAdd(&traced[(blockIdx.x & (RT_TRACED_SLOTS - 1)) * RT_TRACED_STRIDE + 2], (unsigned long long)idle);
     }
     add_work<COUNT>(work, nn, nt);
 }

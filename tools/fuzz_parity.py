@@ -41,14 +41,14 @@ def check_seed(seed, api, OracleScene, np, big=False):
             notes.append("exact: refractive frame within 1e-4 but beyond 1e-5 (max abs %.3g)" % float(np.abs(a[fin] - b[fin]).max()))
     elif not bits_equal(a, b).all():
         frame.append("exact: %d of %d pixels differ" % (int((~bits_equal(a, b).all(axis=-1)).sum()), W * H))
-    if (sb.rays_any, 2 * sb.rays_closest) != (sa.rays_any, sa.rays_closest) and not refr:
-        frame.append("exact: ray counts %d/%d, oracle %d/%d" % (sb.rays_closest, sb.rays_any, sa.rays_closest // 2, sa.rays_any))
-    if sa.reserved_[0]:
-        # the reference reads hit records it never wrote (a NaN ray, a hit at t = +inf): nothing defines such a pixel,
-        # and a difference in this frame is only noted
-        notes += ["%s - the reference's result is undefined here (%d unset hit records)" % (f, sa.reserved_[0]) for f in frame]
-    else:
-        problems += frame
+    # The reference-equivalent call count includes the light rays the reference sends from hits without a record, which
+    # the GPU counts and does not trace; with no such hit the traced rays themselves are equal.
+    if sb.ref_get_hit_calls != sa.rays_closest + sa.rays_any or (not sa.reserved_[0] and sb.rays_any != sa.rays_any):
+        frame.append("exact: get_hit calls %d (traced %d + %d), oracle %d + %d" % (sb.ref_get_hit_calls, sb.rays_closest, sb.rays_any, sa.rays_closest, sa.rays_any))
+    # reserved_[0] of the ORACLE's statistics: get_hit calls that returned true with a record nobody filled (a ray with
+    # a NaN direction, a hit at t = +inf).  The reference's behaviour is undefined there; the oracle draws nothing for
+    # such a ray and the HIP path does the same, so frames are compared all the same.
+    problems += ["%s (%d hits without a record in the oracle's frame)" % (f, sa.reserved_[0]) if sa.reserved_[0] else f for f in frame]
     # the same frame whatever way it is asked for: idle light rays skipped, a part of the frame alone, interleaved rows
     opt.skip_unlit = 1
     b2, _ = g.render_rect(opt, 0, 0, W, H)
@@ -79,7 +79,7 @@ def check_seed(seed, api, OracleScene, np, big=False):
         c, _ = h.render_rect(opt, 0, 0, W, H)
         fin = np.isfinite(a) & np.isfinite(c)
         px = ~(np.isclose(a, c, rtol=1e-5, atol=1e-6) | (np.isnan(a) & np.isnan(c))).all(axis=-1)
-        if px.any() and not sa.reserved_[0]:
+        if px.any():
             notes.append("pruning, %s: %d of %d pixels differ" % (name, int(px.sum()), W * H))
     # a batch of rays: ids, distances, the any-hit answer
     P = np.concatenate([m.pos.reshape(-1, 3) for m in sc.meshes])
