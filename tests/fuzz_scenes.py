@@ -138,6 +138,32 @@ def random_options(seed, exact):
                    jitter_mode=[RT_JITTER_OFF, RT_JITTER_HASH][rng.randint(2)], seed=int(rng.randint(1 << 20)), exact_boxes=int(exact))
 
 
+def random_options_wide(seed, exact):
+    """The corners of the option space random_options leaves out: up to 81 samples per pixel (both replay forms:
+    fused, and in two passes from 16 samples on scenes that spawn rays), up to 16 light rays per hit and light, up to
+    five bounces - on small frames, with the number of children bounded where the ray tree is deep."""
+    rng = np.random.RandomState(seed + 31337)
+    spp = int([1, 2, 3, 4, 4, 5, 6, 9][rng.randint(8)])
+    bounce = int(rng.randint(0, 6))
+    spr = int([0, 1, 2, 3, 5, 8, 15][rng.randint(7 if bounce <= 1 else (5 if bounce == 2 else 3))])
+    side = 20 if spp <= 3 else 10
+    return Options(width=int(rng.randint(4, side + 1)), height=int(rng.randint(4, side + 1)), hfov=float(20 + 80 * rng.rand()),
+                   spp=spp, spr=spr, max_bounce=bounce, max_refrac_bounce=int(rng.randint(1, 7)),
+                   eps=float([1e-4, 1e-3, 1e-2][rng.randint(3)]), ray_eps=float([1e-3, 1e-2, 0.1][rng.randint(3)]),
+                   jitter_mode=[RT_JITTER_OFF, RT_JITTER_HASH][rng.randint(2)], seed=int(rng.randint(1 << 20)), exact_boxes=int(exact))
+
+
+def more_lights(scene, seed):
+    """Up to eight lights (the most a scene may have)."""
+    rng = np.random.RandomState(seed + 999)
+    while len(scene.lights) < rng.randint(1, 9):
+        if rng.rand() < 0.5:
+            scene.lights.append(Light(0, _unit(rng.normal(size=3)), (0.3 * rng.rand(3)).astype(F)))
+        else:
+            scene.lights.append(Light(1, (rng.normal(size=3) * 3).astype(F), (0.3 * rng.rand(3)).astype(F)))
+    return scene
+
+
 def has_refraction(scene):
     used = {m.material for m in scene.meshes}
     return any(scene.materials[k].kind == MAT_REFRAC for k in used)

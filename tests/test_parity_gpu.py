@@ -592,6 +592,19 @@ def test_random_scenes(oracle_mod, first):
     assert not failed
 
 
+def test_random_scenes_wide_options(oracle_mod):
+    """Random scenes again with the options pushed outwards (tests/fuzz_scenes.py::random_options_wide): up to 81
+    samples per pixel - the fused replay, the flat one and the two-pass one all come up -, up to 16 light rays per hit
+    and light, five bounces, eight lights."""
+    from tools.fuzz_parity import check_seed
+    failed = {}
+    for seed in range(0, 30):
+        problems, _ = check_seed(seed, api, oracle_mod.OracleScene, np, wide=True)
+        if problems:
+            failed[seed] = problems
+    assert not failed
+
+
 def test_big_random_scenes(oracle_mod):
     """The same checks on scenes of tens of thousands of triangles in clusters of very different density (deep,
     lopsided trees; tests/fuzz_scenes.py::random_big_scene)."""

@@ -4,7 +4,8 @@ ray counts equal; the pruning traversal - on the host-built and on the device-bu
 but for rays through shared edges and coincident triangles (reported, not judged here), and must never report a farther
 hit than the oracle on a batch of rays (set aside and only noted: a hit of the oracle that lies outside its own needle
 triangle, and rays that graze a triangle at less than 1e-3 - both explained where they are tested).  One line per failing seed, a summary at the end.
-usage: python tools/fuzz_parity.py <first seed> <count> [big]      (big: tens of thousands of triangles per scene)"""
+usage: python tools/fuzz_parity.py <first seed> <count> [big | wide]
+(big: tens of thousands of triangles per scene; wide: up to 81 samples per pixel, 16 light rays, 5 bounces, 8 lights)"""
 import os
 import sys
 import time
@@ -13,15 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def check_seed(seed, api, OracleScene, np, big=False):
-    from tests.fuzz_scenes import random_scene, random_big_scene, random_options, has_refraction
+def check_seed(seed, api, OracleScene, np, big=False, wide=False):
+    from tests.fuzz_scenes import random_scene, random_big_scene, random_options, random_options_wide, more_lights, has_refraction
     from tests.conftest import bits_equal, random_rays
     sc = random_big_scene(seed) if big else random_scene(seed)
+    if wide:
+        sc = more_lights(sc, seed)
     problems, notes = [], []
     o = OracleScene(sc)
     g = api.TracerScene(sc, device_build=False)
     gd = api.TracerScene(sc, device_build=True)
-    opt = random_options(seed, 1)
+    opt = random_options_wide(seed, 1) if wide else random_options(seed, 1)
     W, H = opt.width, opt.height
     a, sa = o.render_rect(opt, 0, 0, W, H)
     b, sb = g.render_rect(opt, 0, 0, W, H)
@@ -151,10 +154,11 @@ def main():
     api.init(0)
     first, count = int(sys.argv[1]), int(sys.argv[2])
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
     bad = noted = 0
     t0 = time.perf_counter()
     for seed in range(first, first + count):
-        problems, notes = check_seed(seed, api, OracleScene, np, big)
+        problems, notes = check_seed(seed, api, OracleScene, np, big, wide)
         for p in problems:
             print("seed %d: FAIL %s" % (seed, p), flush=True)
         for n in notes:
