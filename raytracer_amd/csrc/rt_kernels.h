@@ -337,8 +337,9 @@ RT_HD V3 phong_shade(V3 cl, V3 cp, V3 l, V3 e, V3 n, int p, V3 clambert) {
     c.x = min_std(1.0f, c.x); c.y = min_std(1.0f, c.y); c.z = min_std(1.0f, c.z);
     return c;
 }
-// src/materials.cpp:4-8,28-43,68-88,120-140
-RT_HD V3 apply_shade(const DScene& sc, const RenderParams& P, const Material& M, V3 p, V3 n, const float* sh, uint32_t key) {
+// src/materials.cpp:4-8,28-43,68-88,120-140; sh(li) = the shadow record's entry for light li
+template <class Sh>
+RT_HD V3 apply_shade_with(const DScene& sc, const RenderParams& P, const Material& M, V3 p, V3 n, Sh sh, uint32_t key) {
     if (M.kind == 0) return v3(1.f, 1.f, 0.f);
     V3 r = v3(0, 0, 0);
     V3 view = v3(0, 0, 0);
@@ -348,10 +349,15 @@ RT_HD V3 apply_shade(const DScene& sc, const RenderParams& P, const Material& M,
         const V3 lc = v3p(sc.lights[li].color);
         V3 c_add = lambert_shade(v3p(M.ambient), v3p(M.base), lc, n, l);
         if (M.kind != 1) c_add = phong_shade(lc, v3p(M.spec), l, view, n, (int)M.shininess, c_add);
-        c_add = vscale(c_add, sh[li]);
+        c_add = vscale(c_add, sh(li));
         r = vadd(r, c_add);
     }
     return r;
+}
+struct ShadowRecArray { const float* v; RT_HDM float operator()(int li) const { return v[li]; } };
+RT_HD V3 apply_shade(const DScene& sc, const RenderParams& P, const Material& M, V3 p, V3 n, const float* sh, uint32_t key) {
+    ShadowRecArray a; a.v = sh;
+    return apply_shade_with(sc, P, M, p, n, a, key);
 }
 
 // What a node leaves behind for its children while the replay is below it.
@@ -487,6 +493,27 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
         if (F.refr && F.count == 2) cc = vscale(cc, k == 0 ? F.r_theta : 1 - F.r_theta);   // :368, :382
         ++lvl;
     }
+}
+
+// replay_sample for a frame none of whose materials spawns rays: a sample's walk is its level-0 node alone - no frames
+// of parents, no colour state handed down - and what is left of the generic walk is one shading call.  Same operations
+// in the same order on the same inputs (the sum starts from the zero the generic walk starts from); c is the colour
+// drawn, with weight 1.  false: the sample draws nothing (a primary ray that hit nothing, src/render_thread.cpp:414-430
+// with depth == D, or a hit without a record).
+struct ShadowRecBytes {
+    const uint8_t* u; float rays;
+    RT_HDM float operator()(int li) const { float f = (float)u[li]; f /= rays; return f; }     // :163
+};
+RT_HD bool replay_flat_sample(const DScene& sc, const RenderParams& P, const Level& L, int64_t i, V3& c) {
+    const int tri = L.tri[i];
+    if (tri < 0) return false;
+    const Material M = load_material(sc.mats + res_material(sc, L, tri));
+    const float4 hn = L.hit[i];
+    const NodeIn in = primary_node(sc, P, i);
+    ShadowRecBytes sh; sh.u = L.unocc + i * sc.n_lights; sh.rays = (float)(P.spr + 1);
+    const V3 add = apply_shade_with(sc, P, M, point_at(in.o, in.d, hn.w), f4v(hn), sh, in.key);
+    c = vadd(v3(0, 0, 0), add);
+    return true;
 }
 
 // adds to the pixel at once (src/rasterizer.cpp:92-96)

@@ -151,11 +151,6 @@ __global__ __launch_bounds__(BLOCK) void k_replay(DScene sc, RenderParams P, Lev
 // consecutive lanes (64 / spp^2 pixels per wave), every load is coalesced in node order, and the pixel's lanes then add
 // their colours in the reference's pop order (last sample first) through lane shuffles - the same additions in the
 // same order as the lane-per-pixel loop, with spp^2 times the lanes.
-struct EmitOne {
-    V3 c; float w; int drew;
-    __device__ __forceinline__ void operator()(int, int64_t, V3 col, float weight) { c = col; w = weight; drew = 1; }
-};
-
 __global__ __launch_bounds__(BLOCK) void k_replay_flat(DScene sc, RenderParams P, LevelSet ls, int64_t n_slots, float* rgb_out) {
     const int spp2 = P.spp * P.spp, per_wave = 64 / spp2;
     const int lane = threadIdx.x & 63;
@@ -163,13 +158,13 @@ __global__ __launch_bounds__(BLOCK) void k_replay_flat(DScene sc, RenderParams P
     const int sub = (int)fdiv((uint32_t)lane, P.div_spp2), smp = lane - sub * spp2;
     const int64_t slot = wave * per_wave + sub;
     const bool active = sub < per_wave && slot < n_slots;
-    EmitOne e; e.c = v3(0, 0, 0); e.w = 0.f; e.drew = 0;
-    if (active) replay_sample(sc, P, ls.lv, slot * spp2 + smp, e);
+    V3 c = v3(0, 0, 0);
+    const int drew = (active && replay_flat_sample(sc, P, ls.lv[0], slot * spp2 + smp, c)) ? 1 : 0;
     V3 sum = v3(0, 0, 0), wsum = v3(0, 0, 0);
     for (int k = spp2 - 1; k >= 0; --k) {
         const int src = lane - smp + k;
-        const float cx = __shfl(e.c.x, src, 64), cy = __shfl(e.c.y, src, 64), cz = __shfl(e.c.z, src, 64), w = __shfl(e.w, src, 64);
-        if (__shfl(e.drew, src, 64)) { sum = vadd(sum, v3(cx, cy, cz)); wsum = vadd(wsum, v3(w, w, w)); }
+        const float cx = __shfl(c.x, src, 64), cy = __shfl(c.y, src, 64), cz = __shfl(c.z, src, 64);
+        if (__shfl(drew, src, 64)) { sum = vadd(sum, v3(cx, cy, cz)); wsum = vadd(wsum, v3(1.f, 1.f, 1.f)); }   // a primary ray weighs 1
     }
     if (!active || smp != 0) return;
     const uint32_t tile = (uint32_t)(slot >> 4), tile_y = fdiv(tile, P.div_tiles_x), tile_x = tile - tile_y * (uint32_t)((P.rw + 3) >> 2);
