@@ -368,6 +368,47 @@ struct RFrame {
     V3 c; float contrib, tpc; // colour state handed to the children (src/render_thread.cpp:245-248, :348, :367-382)
 };
 
+// Where the replay keeps the frames of the levels it is below.  The first RT_FRAME_LDS_LEVELS levels live in LDS, two
+// 16-byte words per level and lane laid out [level][word][lane of the wave] (a wave's access to one word is conflict
+// free); deeper levels go to a per-lane array in scratch.  Scratch loads and stores are vector-memory instructions like
+// the record loads this walk consists of - with every frame in scratch they were two fifths of its memory instructions.
+#ifndef RT_FRAME_LDS_LEVELS
+#define RT_FRAME_LDS_LEVELS 5     // 10 KB per wave; 3 / 5 / 8 measured: mirror room 108.1 / 106.7 / 107.0 ms, glass balls 64.5 / 63.6 / 63.9
+#endif
+typedef float rt_f4 __attribute__((ext_vector_type(4)));
+struct FrameStore {
+    RT_LDS_PTR rt_f4* lds;        // this lane's column: word w of level l is lds[(l * 2 + w) * 64]
+    RFrame* spill;                // levels from RT_FRAME_LDS_LEVELS on (indexed by level)
+    RT_HDM void put(int lvl, const RFrame& F) {
+        if (lvl < RT_FRAME_LDS_LEVELS) {
+            rt_f4 a, b;
+            a.x = RT_I2F(F.base); a.y = RT_I2F((F.next & 0xff) | (F.count << 8) | (F.refr << 16)); a.z = F.r_theta; a.w = F.contrib;
+            b.x = F.c.x; b.y = F.c.y; b.z = F.c.z; b.w = F.tpc;
+            lds[(lvl * 2) * 64] = a; lds[(lvl * 2 + 1) * 64] = b;
+        } else spill[lvl] = F;
+    }
+    // next child to pop at this level (-1: none left)
+    RT_HDM int next(int lvl) const {
+        if (lvl < RT_FRAME_LDS_LEVELS) return (int)(int8_t)(RT_F2I(lds[(lvl * 2) * 64].y) & 0xff);
+        return spill[lvl].next;
+    }
+    // the frame, with its next-child counter already moved on; the returned next is the child to pop now
+    RT_HDM RFrame take(int lvl) {
+        RFrame F;
+        if (lvl < RT_FRAME_LDS_LEVELS) {
+            const rt_f4 a = lds[(lvl * 2) * 64], b = lds[(lvl * 2 + 1) * 64];
+            const int pk = RT_F2I(a.y);
+            F.base = RT_F2I(a.x); F.next = (int)(int8_t)(pk & 0xff); F.count = (pk >> 8) & 0xff; F.refr = (pk >> 16) & 1;
+            F.r_theta = a.z; F.contrib = a.w; F.c = v3(b.x, b.y, b.z); F.tpc = b.w;
+            reinterpret_cast<RT_LDS_PTR int32_t*>(lds + (lvl * 2) * 64)[1] = (pk & ~0xff) | ((F.next - 1) & 0xff);
+        } else {
+            F = spill[lvl];
+            spill[lvl].next = F.next - 1;
+        }
+        return F;
+    }
+};
+
 // A material in four 16-byte loads (the array is 64-byte aligned and a material is 64 bytes).
 RT_HD Material load_material(const Material* p) {
     static_assert(sizeof(Material) == 64, "material layout");
@@ -384,11 +425,10 @@ RT_HD Material load_material(const Material* p) {
 // it is shaded (a primary ray that hit nothing has no children), so its value on entry never matters and samples can
 // be replayed independently of each other; the ORDER of the additions to the pixel is what must be kept.
 template <class Emit>
-RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* lv, int64_t g, Emit& emit) {
+RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* lv, int64_t g, Emit& emit, FrameStore& fr) {
     const float Dr = (float)P.Dr;
     float shadow_rec[8];
     for (int q = 0; q < 8; ++q) shadow_rec[q] = 1.f;
-    RFrame fr[RT_MAX_LEVELS];
     int lvl = 0;
     int64_t i = g;
     V3 cc = v3(0, 0, 0);
@@ -458,9 +498,10 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
                 self = vscale(self, contrib);
                 if (depth == P.D) cc = self; else cc = vadd(cc, self);
                 tpc += contrib;
-                RFrame& F = fr[lvl];
+                RFrame F;
                 F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 0; F.r_theta = 0.f;
                 F.c = cc; F.contrib = contrib; F.tpc = tpc;
+                fr.put(lvl, F);
                 has_kids = n_kids > 0;
             } else if (depth <= 0) {                                         // :286-293, :400-406
                 c = cc; draw = true;
@@ -471,9 +512,10 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
                     c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
                     c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);
                 } else c_add = v3(1, 1, 1);
-                RFrame& F = fr[lvl];
+                RFrame F;
                 F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 1; F.r_theta = L.implicit ? L.aux[i] : aux;
                 F.c = vmul(cc, c_add); F.contrib = 1.f; F.tpc = 0.f;
+                fr.put(lvl, F);
                 has_kids = n_kids > 0;
             }
         } else if (tri == -1) {                                              // :414-430; RT_UNSET_HIT draws nothing (:178-180 match no mesh)
@@ -483,11 +525,11 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
         // ---- next ray to pop: the newest pushed one
         if (!has_kids) {
             --lvl;
-            while (lvl >= 0 && fr[lvl].next < 0) --lvl;
+            while (lvl >= 0 && fr.next(lvl) < 0) --lvl;
             if (lvl < 0) break;
         }
-        const RFrame& F = fr[lvl];
-        const int k = fr[lvl].next--;
+        const RFrame F = fr.take(lvl);
+        const int k = F.next;
         i = F.base + k;
         cc = F.c; contrib = F.contrib; tpc = F.tpc;
         if (F.refr && F.count == 2) cc = vscale(cc, k == 0 ? F.r_theta : 1 - F.r_theta);   // :368, :382
@@ -523,12 +565,12 @@ struct EmitSum {
 };
 
 // One pixel: pl = row_in_band * rw + column_in_rect.  Writes rgb_out[pl] = sum(colours) / sum(weights).
-RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out) {
+RT_HD void body_replay(const DScene& sc, const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out, FrameStore& fr) {
     const int spp2 = P.spp * P.spp;
     const int64_t slot = pixel_slot(P, (int)(pl % P.rw), (int)(pl / P.rw));
     EmitSum e; e.sum = v3(0, 0, 0); e.wsum = v3(0, 0, 0);
     // push order of src/render_thread.cpp:57-109 is sample 0 first, so the last sample pops first
-    for (int s = spp2 - 1; s >= 0; --s) replay_sample(sc, P, lv, slot * spp2 + s, e);
+    for (int s = spp2 - 1; s >= 0; --s) replay_sample(sc, P, lv, slot * spp2 + s, e, fr);
     rgb_out[pl * 3 + 0] = e.sum.x / e.wsum.x;
     rgb_out[pl * 3 + 1] = e.sum.y / e.wsum.y;
     rgb_out[pl * 3 + 2] = e.sum.z / e.wsum.z;
@@ -547,9 +589,9 @@ struct EmitChain {
     }
     RT_HDM void operator()(int l, int64_t i, V3 c, float weight) { flush(l, i); plvl = l; pidx = i; pc = c; pw = weight; }
 };
-RT_HD void body_shade(const DScene& sc, const RenderParams& P, const Level* lv, int64_t g) {
+RT_HD void body_shade(const DScene& sc, const RenderParams& P, const Level* lv, int64_t g, FrameStore& fr) {
     EmitChain e; e.lv = lv; e.g = g; e.plvl = -1; e.pidx = 0; e.pc = v3(0, 0, 0); e.pw = 0.f;
-    if (lv[0].tri[g] >= 0) replay_sample(sc, P, lv, g, e);    // a primary ray that hit nothing draws nothing
+    if (lv[0].tri[g] >= 0) replay_sample(sc, P, lv, g, e, fr);    // a primary ray that hit nothing draws nothing
     e.flush(-1, -1);    // closes the chain, or marks the sample as drawing nothing
 }
 RT_HD void body_sum(const RenderParams& P, const Level* lv, int64_t pl, float* rgb_out) {

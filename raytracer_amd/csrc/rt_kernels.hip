@@ -142,9 +142,18 @@ __global__ __launch_bounds__(SPAWN_BLOCK) void k_spawn(DScene sc, RenderParams P
     }
 }
 
+// LDS and scratch parts of the replay's frames (one wave per workgroup)
+#define RT_DECLARE_FRAMES(fr)                                                          \
+    static_assert(BLOCK == 64, "the frame store is laid out for one wave per workgroup"); \
+    __shared__ rt_f4 lds_frames_[RT_FRAME_LDS_LEVELS * 2 * 64];                        \
+    RFrame frame_spill_[RT_MAX_LEVELS];                                                \
+    FrameStore fr;                                                                     \
+    fr.lds = (RT_LDS_PTR rt_f4*)lds_frames_ + threadIdx.x; fr.spill = frame_spill_
+
 __global__ __launch_bounds__(BLOCK) void k_replay(DScene sc, RenderParams P, LevelSet ls, int64_t n_pixels, float* rgb_out) {
     const int64_t pl = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (pl < n_pixels) body_replay(sc, P, ls.lv, pl, rgb_out);
+    RT_DECLARE_FRAMES(fr);
+    if (pl < n_pixels) body_replay(sc, P, ls.lv, pl, rgb_out, fr);
 }
 
 // Replay of a frame that has only level 0 (no material spawns rays), one lane per SAMPLE: the samples of a pixel sit in
@@ -179,7 +188,8 @@ __global__ __launch_bounds__(BLOCK) void k_replay_flat(DScene sc, RenderParams P
 
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, RenderParams P, LevelSet ls, int64_t n) {
     const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (g < n) body_shade(sc, P, ls.lv, g);
+    RT_DECLARE_FRAMES(fr);
+    if (g < n) body_shade(sc, P, ls.lv, g, fr);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_sum(RenderParams P, LevelSet ls, int64_t n_pixels, float* rgb_out) {
