@@ -132,8 +132,11 @@ typedef struct rt_options {
 typedef struct rt_stats {
     uint64_t rays_closest;      /* nearest-hit queries traced (primary + secondary render rays) */
     uint64_t rays_any;          /* any-hit queries traced (light-visibility rays) */
-    uint64_t ref_get_hit_calls; /* get_hit calls the reference would make for the same work
-                                   (it traces every render ray twice, src/render_thread.cpp:82-104,269-280) */
+    uint64_t ref_get_hit_calls; /* get_hit calls the reference would make for the same work: it traces every render
+                                   ray twice (src/render_thread.cpp:82-104,269-280), and it sends light rays this
+                                   library counts without tracing - those rt_options.skip_unlit leaves out, and
+                                   those from a hit whose record the reference never filled (every t it was given
+                                   was +inf or NaN, src/render_thread.cpp:13-19), which start at a non-finite point */
     uint64_t nodes_extend;      /* with count_traversal: 64-byte inner nodes fetched by the nearest-hit kernels */
     uint64_t tris_extend;       /*                       48-byte triangles tested by them */
     uint64_t nodes_shadow;      /* the same for the any-hit kernels */
