@@ -421,7 +421,6 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRa
     st.sp = 0;
     int32_t cur = 0;
     bool found = false;
-    const bool wild = !ANY && !EXACT && !(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < INFINITY);
     for (;;) {
         // ---- descend until a leaf is reached (cur < 0) or nothing is left (cur == RT_NONE)
         while (cur >= 0) {
@@ -449,11 +448,8 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRa
                     found = true;
                 }
                 // passed the test with a t that is +inf or NaN and nothing recorded so far: the reference's get_hit
-                // would answer "hit" and leave its record unset (src/render_thread.cpp:13-19); noted as tri = -2.
-                // On the pruning traversal's own tree only for a ray that is itself not finite (every triangle of any
-                // tree then passes): whether a FINITE ray meets an edge-on triangle whose test divides 0 by 0 depends
-                // on the boxes around it, and widened boxes let through what the reference's never test.
-                else if (!(t < INFINITY) && best.tri == -1 && (EXACT || wild)) best.tri = -2;
+                // would answer "hit" and leave its record unset (src/render_thread.cpp:13-19); noted as tri = -2
+                else if (!(t < INFINITY) && best.tri == -1) best.tri = -2;
             }
         }
         if (st.sp == 0) break;

@@ -194,7 +194,11 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     // no hit: -1, or RT_UNSET_HIT where the reference's get_hit says "hit" without a record (see traverse_oct): such a
     // node draws nothing and has no children, and the light rays the reference sends from its non-finite hit point
     // are counted, not traced
-    const int none = (!hit && meta_type(in.packed) != RAY_NONE && h.tri == RT_UNSET_HIT) ? RT_UNSET_HIT : -1;
+    // On the pruning traversal's own tree only for a ray that is itself not finite (every triangle of any tree then
+    // passes): whether a FINITE ray meets an edge-on triangle whose test divides 0 by 0 depends on the boxes around it,
+    // and widened boxes let through what the reference's never test.
+    const bool any_tree = EXACT || !(fabsf(in.o.x) + fabsf(in.o.y) + fabsf(in.o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < INFINITY);
+    const int none = (!hit && meta_type(in.packed) != RAY_NONE && h.tri == RT_UNSET_HIT && any_tree) ? RT_UNSET_HIT : -1;
     int kind = 0, mat = none;
     if (hit) {
         const V3 n = hit_normal(sc, h);
