@@ -441,8 +441,11 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRa
                 if (n_tris) RT_COUNT_STEP(*n_tris);
                 float t, beta, gamma;
                 if (!tri_test(p0, p1, p2, o, d, t0, ANY ? t1 : fminf(t1, best.t), t, beta, gamma)) continue;
-                // a NaN t (0/0 on a zero-area triangle) passes every comparison of the test; it is never a hit here
-                if (ANY) { if (t == t) return true; }
+                // any-hit with the reference's arithmetic on the reference's tree: whatever passes the test occludes, a
+                // NaN t included (0/0: a zero-area triangle, a needle whose determinant cancels to zero on this ray) -
+                // the reference's boolean (src/render_thread.cpp:158).  On the pruning traversal's own tree a NaN t is
+                // no occluder: which rays reach such a triangle depends on the boxes around it.
+                if (ANY) { if (EXACT || t == t) return true; }
                 else if (t < best.t || (t == best.t && RT_F2I(p2.w) < best.rank)) {
                     best.t = t; best.tri = k; best.rank = RT_F2I(p2.w); best.beta = beta; best.gamma = gamma;
                     found = true;

@@ -38,6 +38,20 @@ def main():
                 print("   oracle tri %d t %r   gpu tri %d t %r" % (trio[i], float(to[i]), trig[i], float(tg[i])))
                 for tri in {int(trio[i]), int(trig[i])} - {-1}:
                     print("   tri %d of %d: %s" % (tri, len(T), T[tri].tolist()))
+        ao, _, _ = o.trace(org, d, 1e-4, 10000.0, any_hit=True)
+        ag, _, _ = g.trace(org, d, 1e-4, 10000.0, any_hit=True, exact_boxes=True)
+        for i in np.nonzero(ao != ag)[0]:
+            print("seed %d any-hit ray %d (%s): org %s dir %s: oracle %r gpu %r; nearest: oracle tri %d t %r" % (seed, i, "corner" if i >= len(org) - k else "free", org[i], d[i], float(ao[i]), float(ag[i]), trio[i], float(to[i])))
+            # which triangles does the reference's test let through on this ray (float32 Cramer, as the oracle does it)
+            f = np.float32
+            for ti, tri in enumerate(T):
+                a_, b_, c_ = tri[0].astype(f), tri[1].astype(f), tri[2].astype(f)
+                ab, ac, ao_ = a_ - b_, a_ - c_, a_ - org[i]
+                dd = d[i]
+                ei_hf = f(ac[1] * dd[2]) - f(dd[1] * ac[2]); gf_di = f(dd[0] * ac[2]) - f(ac[0] * dd[2]); dh_eg = f(ac[0] * dd[1]) - f(ac[1] * dd[0])
+                m = f(f(ab[0] * ei_hf) + f(ab[1] * gf_di)) + f(ab[2] * dh_eg)
+                if abs(m) < 1e-12:
+                    print("   tri %d has determinant %r on this ray: %s" % (ti, float(m), tri.tolist()))
         opt = random_options(seed, 1)
         W, H = opt.width, opt.height
         a, sa = o.render_rect(opt, 0, 0, W, H)

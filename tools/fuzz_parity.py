@@ -135,6 +135,12 @@ def check_seed(seed, api, OracleScene, np, big=False, wide=False):
             notes.append("pruning trace, %s: %d free rays differ in id" % (name, int((~same[:-k]).sum())))
         ap, _, _ = h.trace(org, d, 1e-4, 10000.0, any_hit=True, exact_boxes=False)
         miss = np.isfinite(ao) & ~np.isfinite(ap)
+        # occluded for the oracle by something without a finite distance (the nearest-hit query finds nothing): a NaN t,
+        # which only the reference's arithmetic on the reference's tree takes for an occluder
+        ghost = miss & (trio < 0)
+        if ghost.any():
+            notes.append("pruning any-hit, %s: %d rays occluded for the oracle by a triangle without a finite distance" % (name, int(ghost.sum())))
+        miss &= ~ghost
         if miss.any():
             problems.append("pruning any-hit, %s: %d rays the oracle finds occluded pass" % (name, int(miss.sum())))
     info = gd.check_tree()
