@@ -187,6 +187,14 @@ int rt_scene_check_tree(rt_scene* scene, const rt_mesh_desc* meshes, int n_meshe
 /* Shape of the flattened tree: counts[0]=triangles, [1]=inner nodes, [2]=leaves, [3]=max depth. */
 int rt_scene_info(const rt_scene* scene, int64_t counts[4]);
 
+/* Bounds the memory of rt_render_rect on scenes with reflective or refractive materials.  No counterpart in the
+ * reference, whose RayPool grows by 4000 rays at a time without a bound (src/raypool.cpp:3-24).  The renderer works
+ * through a rectangle in bands of rows and, per band, through the levels of the ray tree; a band whose level would hold
+ * max_items or more light-ray items (rays of the level x lights), or whose queues the GPU cannot allocate, is started
+ * again at half its height (down to four rows; then RT_ERR_UNSUPPORTED).  Frames do not depend on the band height.
+ * Default and maximum 2^31 (the width of an item index); 0 restores the default. */
+int rt_scene_set_level_limit(rt_scene* scene, int64_t max_items);
+
 /* Host-only check of the two tree builders (needs no device): builds, from the same input as rt_scene_create, the
  * flattened form of the reference's trees (BVHNode::BVHNode, src/geometry.cpp:61-153; which = 0) or the
  * surface-area-heuristic tree the pruning traversal walks (which = 1), verifies it (every triangle in exactly one

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
-EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_create_ex", "rt_scene_check_tree", "rt_scene_destroy", "rt_scene_info", "rt_tree_check", "rt_trace",
+EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_create_ex", "rt_scene_check_tree", "rt_scene_destroy", "rt_scene_info", "rt_scene_set_level_limit", "rt_tree_check", "rt_trace",
            "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_render_frame_multi", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg"]
 
 
@@ -51,6 +51,7 @@ def lib():
         L.rt_scene_check_tree.argtypes = [vp, C.POINTER(MeshDesc), C.c_int, C.POINTER(i64)]
         L.rt_scene_destroy.argtypes = [vp]
         L.rt_scene_info.argtypes = [vp, C.POINTER(i64)]
+        L.rt_scene_set_level_limit.argtypes = [vp, i64]
         L.rt_tree_check.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(i64)]
         L.rt_trace.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp]
         L.rt_trace_counted.argtypes = [vp, vp, vp, f32, f32, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp]
@@ -131,6 +132,10 @@ class TracerScene:
         c = (C.c_int64 * 4)()
         _check(lib().rt_scene_info(self._h, c), "rt_scene_info")
         return dict(tris=c[0], inner=c[1], leaves=c[2], depth=c[3])
+
+    def set_level_limit(self, max_items):
+        """Largest number of light-ray items one level of a band's ray tree may hold before the band is split (0: default)."""
+        _check(lib().rt_scene_set_level_limit(self._h, int(max_items)), "rt_scene_set_level_limit")
 
     def trace(self, org, dir, t0, t1, any_hit=False, exact_boxes=False, counted=False, stream=None):
         """Nearest (or any) hit of n rays.  numpy in -> numpy out (t, tri, normal[, nodes, tris])."""

@@ -71,6 +71,11 @@ struct LevelBuf {
 
 #ifndef RT_TWO_PASS_MIN_SAMPLES
 #define RT_TWO_PASS_MIN_SAMPLES 16
+// level-0 samples per band (log2) for scenes whose materials spawn rays, on a GPU with at least 96 GB free: the levels
+// below hold several times as many rays, and every band costs a host round trip per level
+#ifndef RT_BAND_BUDGET_LOG2
+#define RT_BAND_BUDGET_LOG2 27
+#endif
 #endif
 
 enum { RT_N_COUNTERS = 16 + rt::RT_TRACED_SLOTS * rt::RT_TRACED_STRIDE * 2 };   // u32 words of the counter block
@@ -98,6 +103,7 @@ struct rt_scene {
                                              // that passed the depth check; read back by every synchronising call)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..3] per-kernel timing, [4..5] whole call
     hipEvent_t ev_done = nullptr;            // end of the last call's work: the next call's stream waits for it before it
+    int64_t level_limit = (int64_t)1 << 31;  // light-ray items one level may hold (rt_scene_set_level_limit)
     bool pending = false;                    // touches the workspace (calls may come on different streams)
 };
 
@@ -459,6 +465,15 @@ int rt_scene_check_tree(rt_scene* sc, const rt_mesh_desc* meshes, int n_meshes, 
     RT_API_END("rt_scene_check_tree")
 }
 
+
+int rt_scene_set_level_limit(rt_scene* sc, int64_t max_items) {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_scene_set_level_limit: null scene");
+    if (max_items < 0 || max_items > ((int64_t)1 << 31)) return fail(RT_ERR_INVALID, "rt_scene_set_level_limit: 0 (default) .. 2^31");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    sc->level_limit = max_items ? max_items : (int64_t)1 << 31;
+    return RT_OK;
+}
+
 int rt_scene_info(const rt_scene* sc, int64_t counts[4]) {
     if (!sc || !counts) return fail(RT_ERR_INVALID, "rt_scene_info: null argument");
     counts[0] = sc->n_tris; counts[1] = sc->n_inner; counts[2] = sc->n_leaves; counts[3] = sc->max_depth;
@@ -610,7 +625,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         // a band must still be large enough to fill the GPU when there are many samples per pixel
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        budget = (free_b >= ((size_t)96 << 30)) ? (int64_t)1 << 23 : (int64_t)1 << 21;
+        budget = (free_b >= ((size_t)96 << 30)) ? (int64_t)1 << RT_BAND_BUDGET_LOG2 : (int64_t)1 << 21;
     }
     int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
     if (band_rows < rh) band_rows = std::max(4, band_rows & ~3);       // whole 4-row tiles per band
@@ -641,8 +656,13 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     // statistics are asked for: such a frame is three launches and nothing else
     const bool single_level_async = !sc->any_spawning_material && !timing;
 
-    for (int by = 0; by < rh; by += band_rows) {
+    // A band whose deeper levels outgrow the item limit or the memory is started again at half the height: nothing of a
+    // band reaches the frame before its replay, and the band's statistics are added only once it is through.
+    for (int by = 0; by < rh;) {
         const int rows = std::min(band_rows, rh - by);
+        bool too_big = false;
+        uint64_t b_closest = 0, b_any = 0, b_idle = 0, b_work[4] = {0, 0, 0, 0};
+        float b_extend = 0, b_shadow = 0;
         const int64_t n_pix = (int64_t)rows * rw;
         const int64_t n_real = n_pix * spp2;
         int64_t n = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;   // level-0 slots incl. tile padding
@@ -683,29 +703,42 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                 float a = 0, b = 0;
                 HIP_TRY(hipEventElapsedTime(&a, sc->ev[0], sc->ev[1]));
                 HIP_TRY(hipEventElapsedTime(&b, sc->ev[1], sc->ev[2]));
-                ms_extend += a; ms_shadow += b;
+                b_extend += a; b_shadow += b;
             }
-            rays_closest += (uint64_t)(lvl == 0 ? n_real : n);
+            b_closest += (uint64_t)(lvl == 0 ? n_real : n);
             if (timing)
                 for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) {
                     unsigned long long v; memcpy(&v, sc->h_counters + 16 + q * rt::RT_TRACED_STRIDE * 2, 8);
-                    rays_any += v;
+                    b_any += v;
                     memcpy(&v, sc->h_counters + 16 + q * rt::RT_TRACED_STRIDE * 2 + 4, 8);
-                    rays_idle += v;
+                    b_idle += v;
                 }
-            for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); work[q] += v; }
+            for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); b_work[q] += v; }
             int64_t kids = 0;
             for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) kids += sc->h_counters[rt::RT_KIDS_WORD0 + q * rt::RT_TRACED_STRIDE * 2];
             ++lvl;
             if (kids == 0) break;
             if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");
-            if (kids * (int64_t)std::max(nl, 1) >= ((int64_t)1 << 31))
-                return fail(RT_ERR_UNSUPPORTED, "a level of the ray tree exceeds 2^31 light-ray items; render a smaller rectangle");
+            if (kids * (int64_t)std::max(nl, 1) >= sc->level_limit) {
+                if (rows > 4) { too_big = true; break; }
+                return fail(RT_ERR_UNSUPPORTED, "a level of the ray tree exceeds the limit of light-ray items (2^31 unless "
+                                                "rt_scene_set_level_limit lowered it) on a band of four rows; render a narrower rectangle");
+            }
             rc = ensure_level(sc->lv[lvl], kids, nl, false, two_pass);
-            if (rc != RT_OK) return rc;
+            if (rc != RT_OK) {
+                if (rows > 4) { (void)hipGetLastError(); too_big = true; break; }    // out of memory: a lower band needs less
+                return rc;
+            }
             rt::launch_spawn(D, P, L, sc->lv[lvl].L, n, d_counters + 1, s);
             n = kids;
         }
+        if (too_big) {
+            band_rows = std::max(4, (rows / 2) & ~3);
+            continue;
+        }
+        rays_closest += b_closest; rays_any += b_any; rays_idle += b_idle;
+        ms_extend += b_extend; ms_shadow += b_shadow;
+        for (int q = 0; q < 4; ++q) work[q] += b_work[q];
         max_levels = std::max(max_levels, lvl);
         rt::LevelSet ls{};
         ls.lv[0] = level0;
@@ -721,6 +754,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
             float a = 0; HIP_TRY(hipEventElapsedTime(&a, sc->ev[0], sc->ev[1]));
             ms_shade += a;
         }
+        by += rows;
     }
     HIP_TRY(hipGetLastError());
     if (timing) HIP_TRY(hipEventRecord(sc->ev[5], s));

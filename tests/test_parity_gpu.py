@@ -269,6 +269,29 @@ def test_rect_and_band_invariance(bunny_scene):
     assert empty.shape == (20, 0, 3)
 
 
+def test_bands_that_outgrow_the_level_limit_are_split():
+    """A scene with mirrors whose deeper levels exceed the item limit of a level: the band is rendered again at half its
+    height until its levels fit; the frame, the ray counts and the reference-equivalent call count are those of the
+    unsplit frame.  A limit that even a four-row band exceeds is reported."""
+    g = api.TracerScene(scenes.mirror_room())
+    opt = Options(width=192, height=108, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-3, jitter_mode=RT_JITTER_HASH, seed=4)
+    full, st = g.render_rect(opt, 0, 0, 192, 108, stats=True)
+    widest = st.rays_closest                       # far more than any single level of a split band may now hold
+    for limit in (widest // 3, widest // 8, widest // 16):
+        g.set_level_limit(limit)
+        part, st2 = g.render_rect(opt, 0, 0, 192, 108, stats=True)
+        assert bits_equal(full, part).all(), limit
+        assert (st2.rays_closest, st2.rays_any, st2.ref_get_hit_calls) == (st.rays_closest, st.rays_any, st.ref_get_hit_calls)
+    g.set_level_limit(8)
+    with pytest.raises(RuntimeError, match="limit of light-ray items"):
+        g.render_rect(opt, 0, 0, 192, 108)
+    g.set_level_limit(0)
+    again, _ = g.render_rect(opt, 0, 0, 192, 108)
+    assert bits_equal(full, again).all()
+    with pytest.raises(RuntimeError):
+        g.set_level_limit(-1)
+
+
 def test_many_meshes_mixed_materials(oracle_mod):
     """An instanced field (61 meshes, 200 k triangles, Lambert / Phong / refractive at random): the top tree over
     mesh boxes answers like the reference's loop over meshes, and a small frame matches within the refractive bar.
