@@ -122,7 +122,8 @@ class TracerScene:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().rt_scene_destroy(self._h)
+            if _LIB is not None:                      # module globals are gone when the interpreter is shutting down
+                _LIB.rt_scene_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -71,8 +71,8 @@ struct LevelBuf {
 
 #ifndef RT_TWO_PASS_MIN_SAMPLES
 #define RT_TWO_PASS_MIN_SAMPLES 16
-// level-0 samples per band (log2) for scenes whose materials spawn rays, on a GPU with at least 96 GB free: the levels
-// below hold several times as many rays, and every band costs a host round trip per level
+// most level-0 samples per band (log2) for scenes whose materials spawn rays: the levels below hold several times as
+// many rays, and every band costs a host round trip per level
 #ifndef RT_BAND_BUDGET_LOG2
 #define RT_BAND_BUDGET_LOG2 27
 #endif
@@ -625,7 +625,9 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         // a band must still be large enough to fill the GPU when there are many samples per pixel
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        budget = (free_b >= ((size_t)96 << 30)) ? (int64_t)1 << RT_BAND_BUDGET_LOG2 : (int64_t)1 << 21;
+        // the queues of all levels of such a band came to about 600 bytes per level-0 sample on the largest scene measured
+        // (10 M triangles, mixed materials, 3 bounces): a quarter of the free memory at most, within 2^21 .. 2^LOG2
+        budget = std::min<int64_t>((int64_t)1 << RT_BAND_BUDGET_LOG2, std::max<int64_t>((int64_t)1 << 21, (int64_t)(free_b / 2400)));
     }
     int band_rows = (int)std::max<int64_t>(1, std::min<int64_t>(rh, budget / ((int64_t)rw * spp2)));
     if (band_rows < rh) band_rows = std::max(4, band_rows & ~3);       // whole 4-row tiles per band
