@@ -478,6 +478,16 @@ def test_ten_million_triangle_field_sample(oracle_mod):
     assert (np.isnan(a) == np.isnan(b)).all()
     fin = np.isfinite(a)
     assert np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6)
+    # band invariance at the full width and sample count (the bench mode): the lower half of the 4K frame in the default
+    # bands and in bands that a low level limit forces to be split several times over
+    opt.exact_boxes = 0
+    whole, s0 = g.render_rect(opt, 0, 0, 3840, 1080)
+    g.set_level_limit(1 << 24)
+    split, s1 = g.render_rect(opt, 0, 0, 3840, 1080)
+    g.set_level_limit(0)
+    assert bits_equal(whole, split).all()
+    assert (s0.rays_closest, s0.rays_any, s0.ref_get_hit_calls) == (s1.rays_closest, s1.rays_any, s1.ref_get_hit_calls)
+    assert s0.rays_closest > 3840 * 1080 * 64
 
 
 @pytest.mark.parametrize("name,bit_exact", [("bunny_phong_1080p", True), ("mirror_room", True), ("glass_balls", False)])
