@@ -26,7 +26,8 @@
  * Ordering: calls on one scene handle are serialised on the host by a mutex
  * and on the device by an event - a call's stream first waits for the work
  * of the previous call on that handle, whichever stream that ran on.  Calls
- * on different handles are independent.
+ * on different handles are independent (those of rt_render_rect_noalloc share
+ * one array per GPU and are ordered by the library, see there).
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -234,8 +235,12 @@ int rt_render_rect(rt_scene* scene, const rt_options* opt, int x0, int y0, int x
  * device memory, and one 4-row band of the rectangle fits the fixed workspace: ceil(width/4) * 16 * spp^2 samples at
  * (36 + lights) bytes each within 64 MiB; larger ones are refused with RT_ERR_UNSUPPORTED.  Taller rectangles are
  * rendered band by band.  The call makes no hipMalloc/hipFree: its queues live in one 64 MiB array that every GPU the
- * library runs on holds until the process ends.  All calls on one GPU share that array, whatever their scene handle:
- * calls that overlap on one GPU (different streams, or threads, without synchronisation between them) race. */
+ * library runs on holds until the process ends.  All calls on one GPU share that array, whatever their scene handle;
+ * the library orders them itself: a call holds a per-GPU lock while it enqueues its work, and its stream first waits for
+ * the end of the previous such call on that GPU (an event), so handles, streams and host threads may be mixed freely.
+ * On a stream that is being captured into a HIP graph (stats must be NULL: statistics need a host synchronisation) the
+ * call records its kernels and touches none of the library's events; replays of such a graph are then ordered against
+ * other users of the scene handle and of the GPU's array by the caller, like any other use of the caller's buffers. */
 int rt_render_rect_noalloc(rt_scene* scene, const rt_options* opt, int x0, int y0, int x1, int y1,
                            float* rgb_out, rt_stats* stats, void* stream);
 

@@ -184,6 +184,11 @@ int ensure_bytes(void** p, int64_t* cap, int64_t need) {
 // per device and kept.
 unsigned char* g_scratch_ptr[RT_MAX_DEVICES];
 std::mutex g_scratch_mu;
+// Every call that uses a GPU's fixed workspace holds `use` of that GPU while it enqueues its work and makes its stream
+// wait for `done`, the end of the previous such call on that GPU - whatever scene handle, stream or thread that came
+// from.  The event is created with the address (set-up, not the calls, may allocate).
+struct ScratchOrder { std::mutex use; hipEvent_t done = nullptr; bool pending = false; };
+ScratchOrder g_scratch_order[RT_MAX_DEVICES];
 int scratch_address(int dev, unsigned char** out) {
     if (dev < 0 || dev >= RT_MAX_DEVICES) return fail(RT_ERR_UNSUPPORTED, "device index beyond RT_MAX_DEVICES");
     std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -191,10 +196,20 @@ int scratch_address(int dev, unsigned char** out) {
         void* p = nullptr;
         HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned no address for the fixed workspace");
+        HIP_TRY(hipEventCreateWithFlags(&g_scratch_order[dev].done, hipEventDisableTiming));
         g_scratch_ptr[dev] = (unsigned char*)p;
     }
     *out = g_scratch_ptr[dev];
     return RT_OK;
+}
+
+// true while `s` records into a HIP graph instead of running: events of the library must then be neither waited for
+// nor recorded (a recorded one would become a node of the caller's graph, and a later plain call waiting for it would
+// be drawn into the capture)
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
 }
 
 }  // namespace
@@ -245,16 +260,18 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
     if (flat.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
     // the tree the pruning traversal walks: surface-area heuristic on host threads, or (RT_BUILD_TREE_ON_DEVICE, scenes
     // of more than a handful of triangles) a linear hierarchy built on the GPU
-    const bool on_device = (flags & RT_BUILD_TREE_ON_DEVICE) != 0 && flat.tris.size() > 16;
+    bool on_device = (flags & RT_BUILD_TREE_ON_DEVICE) != 0 && flat.tris.size() > 16;
     rt::FlatScene fast;
-    if (!on_device) {
+    auto host_tree = [&]() -> int {
         if (!rt::build_sah_scene(meshes, n_meshes, flat, &fast, &err)) return fail(RT_ERR_INVALID, err);
         if (fast.max_depth + 2 > RT_STACK) return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    }
+        return RT_OK;
+    };
+    int rc;
+    if (!on_device && (rc = host_tree()) != RT_OK) return rc;
 
     rt_scene* sc = new rt_scene();
     (void)hipGetDevice(&sc->device);
-    int rc;
     std::vector<rt::Material> mats(n_materials);
     for (int i = 0; i < n_materials; ++i) {
         static_assert(sizeof(rt::Material) == sizeof(rt_material_desc), "material layouts must match");
@@ -278,25 +295,36 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
         for (size_t k = 0; k < flat.tris.size(); ++k) rank_of[(size_t)flat.info[k].id] = flat.tris[k].rank;
         rt::DeviceTree dt;
         const auto tb0 = std::chrono::steady_clock::now();
-        const bool built = rt::build_lbvh_device(meshes, n_meshes, rank_of.data(), (int64_t)flat.tris.size(), &dt, &err);
+        bool built = rt::build_lbvh_device(meshes, n_meshes, rank_of.data(), (int64_t)flat.tris.size(), &dt, &err);
         if (getenv("RT_AMD_DEBUG_TREE"))
-            fprintf(stderr, "rt_amd: device tree build incl. upload of the triangles %.3f s\n",
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
+            fprintf(stderr, "rt_amd: device tree build incl. upload of the triangles %.3f s%s%s\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count(), built ? "" : " - FAILED: ", built ? "" : err.c_str());
+        // A linear hierarchy is as deep as its keys are alike (many triangles at one spot: up to the key's 63 bits plus
+        // log2 of the duplicates), and the build needs memory of its own.  Neither makes the scene unusable: the host
+        // builder takes over - a slower build, not an error.
+        // (RT_AMD_DEBUG_FAIL_DEVICE_BUILD in the environment throws a finished device tree away: the only way to
+        // exercise the take-over on a GPU with memory to spare)
+        if (built && (dt.max_depth + 2 > RT_STACK || getenv("RT_AMD_DEBUG_FAIL_DEVICE_BUILD"))) { rt::free_device_tree(&dt); built = false; }
         if (!built) {
-            rt_scene_destroy(sc);
-            return fail(RT_ERR_HIP, "device tree build: " + err);
+            (void)hipGetLastError();
+            on_device = false;
+            if ((rc = host_tree()) != RT_OK) { rt_scene_destroy(sc); return rc; }
+        } else {
+            sc->owned.push_back(dt.nodes); sc->owned.push_back(dt.tris); sc->owned.push_back(dt.info); sc->owned.push_back(dt.nrm);
+            sc->d_fast.nodes = dt.nodes; sc->d_fast.tris = dt.tris; sc->d_fast.info = dt.info; sc->d_fast.nrm = dt.nrm;
+            sc->fast_nodes = dt.n_nodes; sc->fast_depth = dt.max_depth;
         }
-        sc->owned.push_back(dt.nodes); sc->owned.push_back(dt.tris); sc->owned.push_back(dt.info); sc->owned.push_back(dt.nrm);
-        sc->d_fast.nodes = dt.nodes; sc->d_fast.tris = dt.tris; sc->d_fast.info = dt.info; sc->d_fast.nrm = dt.nrm;
-        sc->fast_nodes = dt.n_nodes; sc->fast_depth = dt.max_depth;
-        if (dt.max_depth + 2 > RT_STACK) { rt_scene_destroy(sc); return fail(RT_ERR_UNSUPPORTED, "device-built tree deeper than the traversal stack"); }
-    } else if ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
-        (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
-        (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
-        (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK) {
-        rt_scene_destroy(sc);
-        return rc;
-    } else { sc->fast_nodes = (int64_t)fast.nodes.size(); sc->fast_depth = fast.max_depth; }
+    }
+    if (!on_device) {
+        if ((rc = upload(sc, fast.nodes.data(), fast.nodes.size(), &sc->d_fast.nodes)) != RT_OK ||
+            (rc = upload(sc, fast.tris.data(), fast.tris.size(), &sc->d_fast.tris)) != RT_OK ||
+            (rc = upload(sc, fast.info.data(), fast.info.size(), &sc->d_fast.info)) != RT_OK ||
+            (rc = upload(sc, fast.nrm.data(), fast.nrm.size(), &sc->d_fast.nrm)) != RT_OK) {
+            rt_scene_destroy(sc);
+            return rc;
+        }
+        sc->fast_nodes = (int64_t)fast.nodes.size(); sc->fast_depth = fast.max_depth;
+    }
     sc->built_on_device = on_device;
     rt::launch_pack_refs(const_cast<rt::Node64*>(sc->d_fast.nodes), sc->fast_nodes, nullptr);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "packing the tree's references failed"); }
@@ -483,20 +511,31 @@ int rt_scene_info(const rt_scene* sc, int64_t counts[4]) {
 // Start and end of a call's use of the scene's workspace.  Calls on one handle may come on different streams: each
 // call's stream first waits for the end of the previous call's work, recorded in ev_done.
 static int workspace_begin(rt_scene* sc, hipStream_t s) {
-    if (sc->pending) HIP_TRY(hipStreamWaitEvent(s, sc->ev_done, 0));
+    if (sc->pending && !stream_is_capturing(s)) HIP_TRY(hipStreamWaitEvent(s, sc->ev_done, 0));
     return RT_OK;
 }
-static int workspace_end(rt_scene* sc, hipStream_t s) {
-    HIP_TRY(hipEventRecord(sc->ev_done, s));
-    sc->pending = true;
-    return RT_OK;
-}
+// Created once workspace_begin has succeeded: whichever way the call then leaves - the last line or an error return
+// after some work was enqueued - the end of what it enqueued on `s` is recorded, so that the next call on the handle
+// (possibly on another stream) is ordered behind it.  order != NULL: the call also used the GPU's fixed workspace.
+struct WorkspaceScope {
+    rt_scene* sc; hipStream_t s; ScratchOrder* order;
+    WorkspaceScope(rt_scene* sc_, hipStream_t s_, ScratchOrder* order_ = nullptr) : sc(sc_), s(s_), order(order_) {}
+    WorkspaceScope(const WorkspaceScope&) = delete;
+    ~WorkspaceScope() {
+        if (stream_is_capturing(s)) return;
+        if (hipEventRecord(sc->ev_done, s) == hipSuccess) sc->pending = true; else (void)hipGetLastError();
+        if (order && order->done) { if (hipEventRecord(order->done, s) == hipSuccess) order->pending = true; else (void)hipGetLastError(); }
+    }
+};
 // The scene's fault word, fetched together with other results a call waits for anyway.
 static int check_fault(rt_scene* sc, hipStream_t s) {
     uint32_t* h = sc->h_counters + RT_N_COUNTERS;
     HIP_TRY(hipMemcpyAsync(h, sc->d_fault, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (*h) return fail(RT_ERR_UNSUPPORTED, "a traversal stack overflowed: tree deeper than the traversal stack");
+    if (*h) {
+        (void)hipMemsetAsync(sc->d_fault, 0, sizeof(uint32_t), s);      // reported once; the next call starts clean
+        return fail(RT_ERR_UNSUPPORTED, "a traversal stack overflowed: tree deeper than the traversal stack");
+    }
     return RT_OK;
 }
 
@@ -514,6 +553,7 @@ static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0
     float *d_t = t_out, *d_n = nrm_out; int32_t* d_tri = tri_out; uint32_t *d_cn = nodes_out, *d_ct = tris_out;
     int rc = workspace_begin(sc, s);
     if (rc != RT_OK) return rc;
+    WorkspaceScope scope(sc, s);
     if (!dev) {
         // layout of the staging block: org[3n] dir[3n] t[n] nrm[3n] tri[n] cn[n] ct[n]
         rc = ensure_bytes(&sc->d_io, &sc->io_cap, n * 13 * 4);
@@ -537,17 +577,21 @@ static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0
         if (tris_out) HIP_TRY(hipMemcpyAsync(tris_out, d_ct, n * 4, hipMemcpyDeviceToHost, s));
         if ((rc = check_fault(sc, s)) != RT_OK) return rc;       // synchronises the stream
     }
-    return workspace_end(sc, s);
+    return RT_OK;
 }
 
 int rt_trace(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact_boxes,
              float* t_out, int32_t* tri_out, float* nrm_out, void* stream) {
+    RT_API_BEGIN
     return trace_impl(sc, org, dir, t0, t1, n, any_hit, exact_boxes, t_out, tri_out, nrm_out, nullptr, nullptr, stream);
+    RT_API_END("rt_trace")
 }
 
 int rt_trace_counted(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact_boxes,
                      float* t_out, int32_t* tri_out, uint32_t* nodes_out, uint32_t* tris_out, void* stream) {
+    RT_API_BEGIN
     return trace_impl(sc, org, dir, t0, t1, n, any_hit, exact_boxes, t_out, tri_out, nullptr, nodes_out, tris_out, stream);
+    RT_API_END("rt_trace_counted")
 }
 
 // Where the first level's arrays and the counter block live when the caller may not allocate: carved out of one
@@ -558,7 +602,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // rt_render_rect and rt_render_rect_noalloc (fixed != NULL).
 static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats,
-                       void* stream, const FixedWorkspace* fixed) {
+                       void* stream, const FixedWorkspace* fixed, ScratchOrder* order = nullptr) {
     if (!sc || !o || !rgb_out) return fail(RT_ERR_INVALID, "rt_render_rect: null argument");
     if (o->width <= 0 || o->height <= 0 || x0 < 0 || y0 < 0 || x1 > o->width || x0 > x1 || y0 > y1)
         return fail(RT_ERR_INVALID, "rt_render_rect: rectangle outside the image");
@@ -640,6 +684,9 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     const bool two_pass = sc->any_spawning_material && spp2 >= RT_TWO_PASS_MIN_SAMPLES;
     int rc = workspace_begin(sc, s);
     if (rc != RT_OK) return rc;
+    // the GPU's fixed workspace is shared by every handle on it: behind the previous call that used it
+    if (order && order->pending && !stream_is_capturing(s)) HIP_TRY(hipStreamWaitEvent(s, order->done, 0));
+    WorkspaceScope scope(sc, s, order);
     float* d_out = rgb_out;
     if (!out_dev) {
         rc = ensure_bytes((void**)&sc->d_stage, &sc->stage_cap, (int64_t)rw * rh * 12);
@@ -773,7 +820,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         stats->levels = max_levels;
         stats->nodes_extend = work[0]; stats->tris_extend = work[1]; stats->nodes_shadow = work[2]; stats->tris_shadow = work[3];
     }
-    return workspace_end(sc, s);
+    return RT_OK;
 }
 
 int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
@@ -789,10 +836,14 @@ int rt_render_rect_noalloc(rt_scene* sc, const rt_options* o, int x0, int y0, in
     if (!sc) return fail(RT_ERR_INVALID, "rt_render_rect_noalloc: null argument");
     DeviceGuard dg(sc->device);
     if (!dg.ok) return fail(RT_ERR_HIP, "rt_render_rect_noalloc: cannot make the scene's device current");
+    RT_API_BEGIN
     FixedWorkspace fw{nullptr, RT_SCRATCH_BYTES};
     int rc = scratch_address(sc->device, &fw.base);     // looked up by rt_init; here only on a device rt_init never saw
     if (rc != RT_OK) return rc;
-    return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, &fw);
+    ScratchOrder* order = &g_scratch_order[sc->device];
+    std::lock_guard<std::mutex> use(order->use);        // one call at a time enqueues work on this GPU's workspace
+    return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, &fw, order);
+    RT_API_END("rt_render_rect_noalloc")
 }
 
 int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_options* opt, int band_rows, float* rgb_out, rt_stats* stats) {
@@ -810,7 +861,7 @@ int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_option
     std::vector<std::string> msg((size_t)N);
     std::vector<rt_stats> st((size_t)N);
     // one host thread per GPU, like the reference's one thread per tile (src/main.cpp:489-507); joined below
-    auto work = [&](int i) {
+    auto work_body = [&](int i) {
         rt_scene* sc = scenes[i];
         auto bad = [&](int code, const std::string& m) { rc[(size_t)i] = code; msg[(size_t)i] = m; };
         DeviceGuard dg(sc->device);
@@ -845,9 +896,19 @@ int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_option
         if (e == hipSuccess) e = hipStreamSynchronize(sc->own_stream);
         if (e != hipSuccess) return bad(RT_ERR_HIP, hipGetErrorString(e));
     };
+    // nothing may leave a worker thread as an exception (that would end the process), and a thread that cannot be
+    // started leaves its share to the calling thread
+    auto work = [&](int i) {
+        try { work_body(i); }
+        catch (const std::exception& e_) { rc[(size_t)i] = RT_ERR_INVALID; try { msg[(size_t)i] = e_.what(); } catch (...) {} }
+        catch (...) { rc[(size_t)i] = RT_ERR_INVALID; }
+    };
     std::vector<std::thread> pool;
-    for (int i = 1; i < N; ++i) pool.emplace_back(work, i);
+    pool.reserve((size_t)N);
+    int started = 1;
+    try { for (; started < N; ++started) pool.emplace_back(work, started); } catch (...) {}
     work(0);
+    for (int i = started; i < N; ++i) work(i);
     for (auto& t : pool) t.join();
     for (int i = 0; i < N; ++i)
         if (rc[(size_t)i] != RT_OK) return fail(rc[(size_t)i], "rt_render_frame_multi, share " + std::to_string(i) + ": " + msg[(size_t)i]);
@@ -867,6 +928,7 @@ int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_option
 
 int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* stream) {
     if (!rgb || !out || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_resolve_u8: null argument or empty image");
+    RT_API_BEGIN
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)width * height * 3;
     const bool in_dev = is_device_ptr(rgb), out_dev = is_device_ptr(out);
@@ -895,6 +957,7 @@ int rt_resolve_u8(const float* rgb, int width, int height, uint8_t* out, void* s
     if (!out_dev) HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, s));
     if (stg) HIP_TRY(hipStreamSynchronize(s));
     return RT_OK;
+    RT_API_END("rt_resolve_u8")
 }
 
 }  // extern "C"
