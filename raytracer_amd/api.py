@@ -109,6 +109,7 @@ class TracerScene:
             _check(lib().rt_scene_create_ex(meshes, len(scene.meshes), mats, len(scene.materials), lights,
                                             len(scene.lights), C.byref(cam), 1 if device_build else 0, C.byref(h)), "rt_scene_create_ex")
         self._h = h
+        self._destroy = lib().rt_scene_destroy        # bound now: at interpreter shutdown module globals and builtins may be gone
         self.scene = scene
 
     def check_tree(self):
@@ -121,13 +122,19 @@ class TracerScene:
                     built_on_device=bool(c[7]))
 
     def close(self):
-        if getattr(self, "_h", None):
-            if _LIB is not None:                      # module globals are gone when the interpreter is shutting down
-                _LIB.rt_scene_destroy(self._h)
-            self._h = None
+        """Frees the scene's device memory.  Safe to call twice, from __del__, and while the interpreter shuts down (it
+        touches nothing but this object's own attributes)."""
+        d = self.__dict__
+        h, destroy = d.get("_h"), d.get("_destroy")
+        d["_h"] = None
+        if h and destroy is not None:
+            destroy(h)
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except:     # noqa: E722  (nothing may escape a finaliser, and at shutdown even exception classes may be gone)
+            pass
 
     def info(self):
         c = (C.c_int64 * 4)()

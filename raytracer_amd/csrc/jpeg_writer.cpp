@@ -84,13 +84,16 @@ void marker(std::vector<uint8_t>& o, uint8_t m, size_t payload) {
 }
 
 // 8x8 forward DCT (separable, float), input level-shifted samples, output in natural order
-void fdct8x8(const float in[64], float out[64]) {
-    static float c[8][8]; static bool init = false;
-    if (!init) {
+struct DctBasis {
+    float c[8][8];
+    DctBasis() {
         for (int u = 0; u < 8; ++u)
             for (int x = 0; x < 8; ++x) c[u][x] = (u == 0 ? std::sqrt(0.125f) : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
-        init = true;
     }
+};
+void fdct8x8(const float in[64], float out[64]) {
+    static const DctBasis basis;          // a function-local static is initialised once, also with several threads encoding
+    const float (*c)[8] = basis.c;
     float tmp[64];
     for (int y = 0; y < 8; ++y)
         for (int u = 0; u < 8; ++u) { float s = 0; for (int x = 0; x < 8; ++x) s += in[y * 8 + x] * c[u][x]; tmp[y * 8 + u] = s; }

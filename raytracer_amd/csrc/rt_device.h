@@ -328,8 +328,9 @@ struct StackLds {
     RT_HDM void push(int32_t v) {
         if (sp < RT_LDS_SLOTS) lds[sp * RT_BLOCK] = v;
         else if (sp < RT_STACK) spill[sp - RT_LDS_SLOTS] = v;
-        else *fault = 1u;    // the subtree is lost; the host checks tree depth against RT_STACK before any launch, so
-                             // this only fires if that check and the tree disagree, and the host then reports it
+        else { *fault = 1u; return; }   // the subtree is lost and sp stays put, so every pop stays inside the arrays; the
+                                        // host checks tree depth against RT_STACK before any launch, so this only fires
+                                        // if that check and the tree disagree, and the host then reports it
         ++sp;
     }
     RT_HDM int32_t pop() {
@@ -360,12 +361,16 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
     const float tn = f_ * ak_jb + e_ * jc_al + d_ * bl_kc;
     const float gn = i_ * ak_jb + h_ * jc_al + g_ * bl_kc;
     const float bn = j_ * ei_hf + k_ * gf_di + l_ * dh_eg;
-    // estimates; a NaN estimate fails every comparison below and so falls through to the exact path
-    const float te = -(tn * rm), ge = gn * rm, be = bn * rm;
-    const float slack = 1e-4f;
-    if (te < t0 - slack * fabsf(t0) - 1e-30f || te > tlim + slack * fabsf(tlim)) return false;
-    if (ge < -slack || ge > 1.f + slack) return false;
-    if (be < -slack || be + ge > 1.f + 2.f * slack) return false;
+    // estimates; a NaN estimate fails every comparison below and so falls through to the exact path.  Only a reciprocal
+    // that is a normal number estimates anything: the hardware reciprocal of a subnormal determinant is +-inf and that
+    // of a huge one is flushed to zero, while the exact quotients below can still be finite and inside the ranges.
+    if (__builtin_amdgcn_classf(rm, 0x108)) {       // -normal | +normal
+        const float te = -(tn * rm), ge = gn * rm, be = bn * rm;
+        const float slack = 1e-4f;
+        if (te < t0 - slack * fabsf(t0) - 1e-30f || te > tlim + slack * fabsf(tlim)) return false;
+        if (ge < -slack || ge > 1.f + slack) return false;
+        if (be < -slack || be + ge > 1.f + 2.f * slack) return false;
+    }
     const float t = tn / -m;
     if (t < t0 || t > tlim) return false;
     const float gamma = gn / m;

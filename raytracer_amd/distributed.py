@@ -92,6 +92,11 @@ def run_pipelined(steps, render, gather, locals_, stacks, streams=None):
     def on(b):
         return torch.cuda.stream(streams[b]) if streams else _NullContext()
 
+    if streams:
+        # the buffers were created (and zero-filled) on the caller's stream: the side streams start behind it
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+
     for k in range(steps):
         b = k % n
         with on(b):
@@ -109,6 +114,10 @@ def run_pipelined(steps, render, gather, locals_, stacks, streams=None):
     if streams:
         for st in streams:                              # the caller's stream continues after every frame is complete
             torch.cuda.current_stream().wait_stream(st)
+        if frame is not None and frame.is_cuda:
+            # the frame was allocated on a side stream; the caching allocator must not hand its memory to later
+            # side-stream work while the caller's stream still reads it
+            frame.record_stream(torch.cuda.current_stream())
     return frame
 
 

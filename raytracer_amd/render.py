@@ -6,8 +6,9 @@
 
 The scene is a baked .rtscene (tools/bake_fbx.py makes one from the reference's FBX input); the option file has the
 reference's keys (-dispw -disph -hfov -spp -spr -bounce -rbounce -eps -reps -mpbs).  The report lines are the
-reference's.  The image is written as PNG or binary PPM (by extension); the reference's JPEG encoder is not part of
-this package.  --blocks renders display block by display block (-mpbs pixels square) like the reference's progressive
+reference's.  The image is written by extension: .jpg (the default, like the reference's save_jpg, src/main.cpp:148-180:
+baseline JPEG, quality 90, 4:4:4, comment "Render Result", through the library's own encoder rt_save_jpeg), .png or binary
+.ppm.  --blocks renders display block by display block (-mpbs pixels square) like the reference's progressive
 loop; the default is one call for the whole frame, which is the same image."""
 import argparse
 import glob

@@ -90,6 +90,36 @@ def check_reflection(refl_rabbit, rabbit, teal2):
     assert iou(tr, refl_rabbit) >= 0.8
 
 
+def check_ground_luma(frame, ground, luma, min_corr=0.90, max_resid=0.003):
+    """frame: [270, 480, 3] float render of the shipped scene at the image's settings (-spp 2 -spr 3 -reps 0.1, jitter on);
+    ground: [270, 480] bool, the pixel centre's nearest hit is on the ground mesh; luma: image 1's max(R, G, B) at those
+    pixel centres.  The image was made with a second light and other colours than the committed scene file, so values do
+    not compare - but the ground is one flat Lambert surface, so both pictures are, on it, an affine function of ONE
+    thing: the fraction of light rays that reach light 0 (src/render_thread.cpp:146-165).  One scale and one offset fitted
+    over all ground pixels must therefore leave nothing but JPEG noise: this pins the soft-shadow stage - where the
+    penumbra lies and how wide the ray jitter of src/ray.cpp:47-61 makes it - against a picture the reference rendered.
+    Returns (correlation, mean absolute residual of the fit)."""
+    g = ground.copy()                                  # away from the ground's outline (JPEG ringing, mixed pixels)
+    g[1:] &= ground[:-1]; g[:-1] &= ground[1:]; g[:, 1:] &= ground[:, :-1]; g[:, :-1] &= ground[:, 1:]
+    mine = np.nan_to_num(frame).max(axis=2)[g].astype(np.float64)
+    ref = luma[g].astype(np.float64) / 255.0
+    A = np.stack([mine, np.ones_like(mine)], 1)
+    co = np.linalg.lstsq(A, ref, rcond=None)[0]
+    resid = float(np.abs(A @ co - ref).mean())
+    corr = float(np.corrcoef(mine, ref)[0, 1])
+    assert g.sum() > 50000 and co[0] > 0.2
+    assert corr >= min_corr and resid <= max_resid, (corr, resid)
+    return corr, resid
+
+
+def ground_mask_480(tracer, scene):
+    """[270, 480] bool: nearest hit of the centre of pixel (2 + 4x, 2 + 4y) of the 1920x1080 frame is on the ground."""
+    org, d, shape = centre_rays(scene.camera, step=4, first=2)
+    _, tri, _ = tracer.trace(org, d, 1e-4, np.inf)
+    lo, hi = mesh_range(scene, "ground")
+    return ((tri >= lo) & (tri < hi)).reshape(shape)
+
+
 def run_all(tracer, scene, fx=None):
     """All of the above from primary, light and mirror rays traced by `tracer`."""
     fx = fx or load_fixture()

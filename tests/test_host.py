@@ -191,9 +191,35 @@ def test_jpeg_writer_matches_the_reference_save_path(tmp_path):
     # a flat black frame (the reference's background) decodes to exact black
     api.save_jpeg(p, np.zeros((16, 24, 3), np.uint8))
     assert (np.asarray(Image.open(p)) == 0).all()
-    # the reference's own result images use the same container choices
-    ref = os.path.join(GOLDEN, "ref_images.npz")
-    assert os.path.exists(ref)
+
+
+def test_jpeg_header_segments_equal_the_reference_files_byte_for_byte():
+    """Everything of a result file that does not depend on the pixels, against files the reference's own save_jpg wrote
+    (six of its docs&images/render_result_*.jpg; extracted by tests/golden/make_jpeg_segment_fixtures.py): SOI, APP0
+    (JFIF 1.1, no density), COM "Render Result", DQT (Annex K tables at quality 90, src/toojpeg.cpp:413-417, both in one
+    segment, zig-zag order), SOF0 (8 bit, size, three components 1x1 = 4:4:4), DHT (the four standard tables in one
+    segment) and the SOS header - 624 bytes, in this order.  The entropy-coded bytes after them depend on the encoder's
+    DCT and rounding and are checked through a decoder in the test above."""
+    import ctypes as C
+    z = np.load(os.path.join(GOLDEN, "ref_jpeg_headers.npz"))
+    names = [k for k in z.files if not k.endswith("_size")]
+    assert len(names) == 6
+    L = api.lib()
+    for k in names:
+        w, h = (int(v) for v in z[k + "_size"])
+        ref = z[k]
+        assert len(ref) == 624
+        img = np.full((h, w, 3), 37, np.uint8)
+        buf = np.empty(w * h // 4 + 4096, np.uint8)
+        n = C.c_int64()
+        assert L.rt_encode_jpeg(img.ctypes.data, w, h, 90, b"Render Result", buf.ctypes.data, buf.size, C.byref(n)) == 0
+        assert n.value > 624 and (buf[:624] == ref).all(), k
+    # and they do depend on what they should: another quality or comment changes DQT / COM
+    n = C.c_int64()
+    buf = np.empty(1 << 16, np.uint8)
+    img = np.zeros((16, 16, 3), np.uint8)
+    assert L.rt_encode_jpeg(img.ctypes.data, 16, 16, 75, b"Render Result", buf.ctypes.data, buf.size, C.byref(n)) == 0
+    assert (buf[:20 + 17] == z[names[0]][:37]).all() and not (buf[37:37 + 134] == z[names[0]][37:37 + 134]).all()
 
 
 def test_baker_generates_smooth_normals_for_meshes_without_normals():

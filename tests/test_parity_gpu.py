@@ -112,6 +112,59 @@ def test_zero_area_triangle_in_a_mesh_of_its_own(oracle_mod):
         assert bits_equal(img_o, img_g).all()
 
 
+def test_triangles_with_subnormal_determinants(oracle_mod):
+    """Triangles with edges around 1e-20 at the origin: the determinant of the reference's Cramer test (edge x edge . d)
+    is then a SUBNORMAL float on nearly every ray that meets one, while the quotients t, beta and gamma are ordinary
+    numbers.  The hardware reciprocal of a subnormal is infinite, so the reciprocal estimate that normally rejects far-off
+    triangles early must stand aside and the exact divisions decide: ids, distances and normals bit-equal to the oracle
+    in the reference-arithmetic mode, the any-hit answer equal, the pruning mode never farther."""
+    from tests.test_oracle import one_mesh_scene
+    from raytracer_amd.scene import Mesh
+    F = np.float32
+    rng = np.random.RandomState(11)
+    n, m = 300, 4000
+    a = (rng.rand(n, 1, 3) - 0.5) * 2e-19
+    size = 10 ** rng.uniform(-21, -18.5, size=(n, 1, 1))
+    pos = (a + (rng.rand(n, 3, 3) - 0.5) * size).astype(F)
+    sc = one_mesh_scene([[[-3, -3, -1], [3, -3, -1], [0, 3, -1]]])            # something ordinary behind the specks
+    # every speck a mesh of its own: where products underflow to a determinant of exactly zero the test divides 0 by 0,
+    # and inside ONE mesh the reference's pairwise merge lets such a NaN record hide its siblings' hits
+    # (src/geometry.cpp:171-175, see test_zero_area_triangle_in_a_mesh_of_its_own); across meshes get_hit drops it
+    for k in range(n):
+        sc.meshes.append(Mesh("speck%d" % k, 0, pos[k:k + 1], np.tile(np.array([0, 0, 1], F), (1, 3, 1))))
+    org = rng.normal(size=(m, 3))
+    org = (org / np.linalg.norm(org, axis=1, keepdims=True) * rng.uniform(0.3, 2, size=(m, 1))).astype(F)
+    corner = pos.reshape(-1, 3)[rng.randint(3 * n, size=m)].astype(np.float64)
+    inside = (pos[rng.randint(n, size=m)].astype(np.float64) * rng.dirichlet([1, 1, 1], size=m)[:, :, None]).sum(1)
+    tgt = np.where((np.arange(m) % 2 == 0)[:, None], corner, inside)
+    d = tgt - org.astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+    g, o = _pair(sc, oracle_mod)
+    to, trio, nro = o.trace(org, d, 1e-4, np.inf)
+    hit = trio >= 1
+    assert hit.sum() > 1000                                                   # the specks are hit, and then ...
+    T = np.concatenate([msh.pos for msh in sc.meshes])[trio[hit]]
+    det = ((T[:, 0] - T[:, 1]).astype(F) * np.cross((T[:, 0] - T[:, 2]).astype(F), d[hit])).sum(1)
+    assert (np.abs(det) < 1.17549435e-38).mean() > 0.99                       # ... through a subnormal determinant
+    ao, _, _ = o.trace(org, d, 1e-4, 10000.0, any_hit=True)
+    tg, trig, nrg = g.trace(org, d, 1e-4, np.inf, exact_boxes=True)
+    assert (trig == trio).all() and bits_equal(tg, to).all() and bits_equal(nrg, nro).all()
+    ag, _, _ = g.trace(org, d, 1e-4, 10000.0, any_hit=True, exact_boxes=True)
+    assert (ag == ao).all()
+    # The pruning traversal has no "never farther" bar here: three hundred specks sit at one point, and a distance that is
+    # a quotient of two numbers of nine significant bits is off by tens of per cent (the same point comes out at t = 1.0
+    # from one triangle and 1.29 from the next), so which of them is "nearest" is noise that pruning by box distance
+    # cannot and need not follow.  What holds: the same triangle gives the same bits, and a ray that hits something for
+    # the oracle hits something.
+    tp, trip, nrp = g.trace(org, d, 1e-4, np.inf, exact_boxes=False)
+    same = trip == trio
+    assert bits_equal(tp[same], to[same]).all() and bits_equal(nrp[same], nro[same]).all()
+    assert (trip >= 0)[trio >= 0].all()
+    far = np.where(trio >= 1)[0]
+    true_dist = np.linalg.norm(org, axis=1)                                    # the specks are at the origin
+    assert (np.abs(tp[far] - true_dist[far]) <= 0.6 * true_dist[far]).all()
+
+
 def test_tie_rules_on_gpu(oracle_mod):
     from tests.test_oracle import one_mesh_scene
     from raytracer_amd.scene import Mesh
@@ -586,6 +639,31 @@ def test_device_built_tree(oracle_mod, name):
     b, sb = dev.render_rect(opt, 0, 0, 96, 54)
     assert (~bits_equal(a, b).all(axis=-1)).sum() <= 1
     assert abs(sa.rays_any - sb.rays_any) <= 1e-3 * sa.rays_any
+
+
+def test_failed_device_build_falls_back_to_the_host_builder(oracle_mod, monkeypatch):
+    """A device build that fails (no memory for it, a hierarchy deeper than the traversal stack) is not an error: the
+    host builder takes over and the scene reports that its tree was not built on the device.  Many coincident triangles
+    (equal sort keys, the deepest hierarchies) must build either way."""
+    sc = scenes.mirror_room(4, sphere_res=6)
+    tri = np.array([[[0.1, 0.2, 0.3], [0.4, 0.2, 0.3], [0.1, 0.6, 0.35]]], np.float32)
+    from raytracer_amd.scene import Mesh
+    sc.meshes.append(Mesh("pile", 0, np.repeat(tri, 3000, 0), np.tile(np.array([0, 0, 1], np.float32), (3000, 3, 1))))
+    dev = api.TracerScene(sc, device_build=True)
+    assert dev.check_tree()["reached_tris"] == sc.n_tris
+    monkeypatch.setenv("RT_AMD_DEBUG_FAIL_DEVICE_BUILD", "1")
+    fell = api.TracerScene(sc, device_build=True)
+    monkeypatch.delenv("RT_AMD_DEBUG_FAIL_DEVICE_BUILD")
+    info = fell.check_tree()
+    assert not info["built_on_device"] and info["reached_tris"] == sc.n_tris
+    o = oracle_mod.OracleScene(sc)
+    P = np.concatenate([m.pos.reshape(-1, 3) for m in sc.meshes])
+    org, d = random_rays(8000, 9, center=P.mean(0), spread=2.0 * float(np.abs(P - P.mean(0)).max()))
+    to, trio, _ = o.trace(org, d, 1e-3, np.inf)
+    for g in (dev, fell):
+        tg, trig, _ = g.trace(org, d, 1e-3, np.inf, exact_boxes=False)
+        same = trig == trio
+        assert same.mean() >= 0.9999 and bits_equal(tg[same], to[same]).all()
 
 
 def test_calls_on_one_handle_from_two_streams_do_not_race():

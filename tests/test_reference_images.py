@@ -25,6 +25,27 @@ def test_a_mirrored_camera_would_be_caught(oracle_mod, bunny_scene):
         ric.run_all(oracle_mod.OracleScene(sc), sc)
 
 
+def test_soft_shadow_on_the_ground_matches_the_reference_image(oracle_mod, bunny_scene):
+    """Image 1's luminance on the ground against the oracle's frame at the image's settings: one affine map explains it
+    to within JPEG noise (mean residual below one 8-bit step).  Not vacuous: hard shadows (-spr 0), no jitter, a fifth
+    of the ray jitter, or a light mirrored in x all fit worse or not at all."""
+    fx = ric.load_fixture()
+    o = oracle_mod.OracleScene(bunny_scene)
+    ground = ric.ground_mask_480(o, bunny_scene)
+    base = dict(width=480, height=270, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-4, ray_eps=0.1, jitter_mode=RT_JITTER_HASH, seed=1)
+    img, _, _ = o.render_frame_mt(Options(**base), 8)
+    corr, resid = ric.check_ground_luma(img, ground, fx["luma1"])
+    for kw in (dict(spr=0), dict(jitter_mode=RT_JITTER_OFF), dict(ray_eps=0.02)):
+        other, _, _ = o.render_frame_mt(Options(**dict(base, **kw)), 8)
+        with pytest.raises(AssertionError):
+            ric.check_ground_luma(other, ground, fx["luma1"])
+    sc = scenes.bunny()
+    sc.lights[0].vec = (sc.lights[0].vec * np.array([-1, 1, 1])).astype(np.float32)
+    flipped, _, _ = oracle_mod.OracleScene(sc).render_frame_mt(Options(**base), 8)
+    with pytest.raises(AssertionError):
+        ric.check_ground_luma(flipped, ground, fx["luma1"])
+
+
 def test_counts_measured_on_the_compiled_reference(oracle_mod, bunny_scene):
     """Numbers recorded from runs of the unmodified reference objects on this scene (before this build began):
     13 568 of 20 736 pixel-centre primary rays hit at 192x108, hfov 60; a 480x270 frame at -spp 2 -spr 3 makes about
@@ -69,6 +90,15 @@ def test_hip_path_matches_the_reference_result_images(bunny_scene):
     opt = Options(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=1)
     frame, _ = g.render_rect(opt, 0, 0, 1920, 1080)
     ric.frame_mask_check(frame, fx)
+    # the soft shadow on the ground, from the HIP path's own frame at a quarter of the size
+    class Tq:
+        def trace(self, org, d, t0, t1, any_hit=False):
+            return g.trace(org, d, t0, t1, any_hit=any_hit, exact_boxes=False)
+    small = Options(width=480, height=270, hfov=60, spp=2, spr=3, max_bounce=3, eps=1e-4, ray_eps=0.1, jitter_mode=RT_JITTER_HASH, seed=1)
+    for exact in (0, 1):
+        small.exact_boxes = exact
+        q, _ = g.render_rect(small, 0, 0, 480, 270)
+        ric.check_ground_luma(q, ric.ground_mask_480(Tq(), bunny_scene), fx["luma1"])
     # the second image's configuration: every pixel that image 2 shows lit is drawn
     g2 = api.TracerScene(scenes.bunny(phong_surroundings=True))
     opt2 = Options(width=1920, height=1080, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3, jitter_mode=RT_JITTER_HASH, seed=1)

@@ -21,8 +21,10 @@ for k, c in sorted(out.items()):
     g = d.get
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
         d["lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
-    if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
-        d["valu_busy_frac_est"] = g("SQ_ACTIVE_INST_VALU") * 4 / g("SQ_BUSY_CYCLES") / 4   # per-SE busy cycles, quad-cycles
+    if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+        # vector instructions issued over what 1024 SIMDs can issue in the kernel's active cycles (one wave64 instruction
+        # per SIMD per 2 cycles); SQ_BUSY_CYCLES is summed over shader engines and is no denominator for this
+        d["valu_issue_frac"] = g("SQ_INSTS_VALU") / (1024 * g("GRBM_GUI_ACTIVE") / 2.0)
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
         d["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
