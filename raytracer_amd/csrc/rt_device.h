@@ -363,14 +363,14 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
     const float bn = j_ * ei_hf + k_ * gf_di + l_ * dh_eg;
     // estimates; a NaN estimate fails every comparison below and so falls through to the exact path.  Only a reciprocal
     // that is a normal number estimates anything: the hardware reciprocal of a subnormal determinant is +-inf and that
-    // of a huge one is flushed to zero, while the exact quotients below can still be finite and inside the ranges.
-    if (__builtin_amdgcn_classf(rm, 0x108)) {       // -normal | +normal
-        const float te = -(tn * rm), ge = gn * rm, be = bn * rm;
-        const float slack = 1e-4f;
-        if (te < t0 - slack * fabsf(t0) - 1e-30f || te > tlim + slack * fabsf(tlim)) return false;
-        if (ge < -slack || ge > 1.f + slack) return false;
-        if (be < -slack || be + ge > 1.f + 2.f * slack) return false;
-    }
+    // of one beyond 8.5e37 is flushed to zero, while the exact quotients below can still be finite and inside the ranges.
+    // (A select, not a branch around the comparisons: 0.3 % against 2.5 % of the light-ray kernel.)
+    const float rme = __builtin_amdgcn_classf(rm, 0x108) ? rm : __builtin_nanf("");      // -normal | +normal
+    const float te = -(tn * rme), ge = gn * rme, be = bn * rme;
+    const float slack = 1e-4f;
+    if (te < t0 - slack * fabsf(t0) - 1e-30f || te > tlim + slack * fabsf(tlim)) return false;
+    if (ge < -slack || ge > 1.f + slack) return false;
+    if (be < -slack || be + ge > 1.f + 2.f * slack) return false;
     const float t = tn / -m;
     if (t < t0 || t > tlim) return false;
     const float gamma = gn / m;

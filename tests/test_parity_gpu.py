@@ -165,6 +165,49 @@ def test_triangles_with_subnormal_determinants(oracle_mod):
     assert (np.abs(tp[far] - true_dist[far]) <= 0.6 * true_dist[far]).all()
 
 
+def test_triangles_with_determinants_beyond_the_reciprocal(oracle_mod):
+    """The other end: triangles with edges around 1.2e19 whose determinant lands between 8.5e37 and the largest float.
+    The hardware reciprocal of such a number is a subnormal, which it flushes to zero - an estimate of zero for every
+    quotient - while the exact quotients are ordinary (rays that start within a unit of the triangle's first corner and
+    hit the wedge beside it).  As above: the estimate stands aside, the exact divisions decide, bit-equal to the oracle."""
+    from tests.test_oracle import one_mesh_scene
+    from raytracer_amd.scene import Mesh
+    F = np.float32
+    rng = np.random.RandomState(5)
+    n, per = 60, 40
+    sc = one_mesh_scene([[[-3, -3, -40], [3, -3, -40], [0, 3, -40]]])
+    org, d = [], []
+    for k in range(n):
+        a = rng.rand(3) - 0.5
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        w = rng.normal(size=3); w -= u * (w @ u); w /= np.linalg.norm(w)
+        v = 0.3 * u + 0.95 * w; v /= np.linalg.norm(v)                       # a wide corner: sine about 0.95
+        L1, L2 = rng.uniform(1.0e19, 1.4e19, size=2)
+        tri = np.stack([a, a + L1 * u, a + L2 * v]).astype(F)
+        sc.meshes.append(Mesh("huge%d" % k, 0, tri[None], np.tile(np.array([0, 0, 1], F), (1, 3, 1))))
+        nrm = np.cross(u, v); nrm /= np.linalg.norm(nrm)
+        for _ in range(per):
+            q = a + rng.uniform(0.05, 1.0) * (rng.uniform(0.1, 0.9) * u + rng.uniform(0.1, 0.9) * v)     # inside the wedge at a
+            side = 1.0 if rng.rand() < 0.5 else -1.0
+            e = q + side * nrm * rng.uniform(0.3, 1.5) + 0.2 * rng.normal(size=3)
+            dd = q - e
+            org.append(e); d.append(dd / np.linalg.norm(dd))
+    org, d = np.array(org, F), np.array(d, F)
+    g, o = _pair(sc, oracle_mod)
+    to, trio, nro = o.trace(org, d, 1e-4, np.inf)
+    hit = trio >= 1
+    assert hit.mean() > 0.5
+    T = np.concatenate([msh.pos for msh in sc.meshes])[trio[hit]]
+    det = np.abs(((T[:, 0] - T[:, 1]).astype(F) * np.cross((T[:, 0] - T[:, 2]).astype(F), d[hit])).sum(1))
+    assert ((det > 8.6e37) & np.isfinite(det)).sum() > 800                    # where the hardware reciprocal is zero
+    for exact in (True, False):
+        tg, trig, nrg = g.trace(org, d, 1e-4, np.inf, exact_boxes=exact)
+        assert (trig == trio).all() and bits_equal(tg, to).all() and bits_equal(nrg, nro).all()
+        ag, _, _ = g.trace(org, d, 1e-4, 1e30, any_hit=True, exact_boxes=exact)
+        ao, _, _ = o.trace(org, d, 1e-4, 1e30, any_hit=True)
+        assert (ag == ao).all()
+
+
 def test_tie_rules_on_gpu(oracle_mod):
     from tests.test_oracle import one_mesh_scene
     from raytracer_amd.scene import Mesh
