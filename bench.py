@@ -121,6 +121,10 @@ def parse_args(argv):
                          "frame is shared by several ranks - a rank's share is too small to keep its GPU busy by itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the per-configuration frame times of the other workloads")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline block (profiling runs that only want the frames)")
+    ap.add_argument("--scale", type=float, default=1.0,
+                    help="render the workload at this fraction of its width and height (rehearsals of the heavy workloads; a "
+                         "scaled run is not the benchmark and says so in config.scale)")
     ap.add_argument("--verify", action="store_true",
                     help="check that the gathered frame equals the same frame rendered whole on this rank")
     return ap.parse_args(argv)
@@ -157,9 +161,16 @@ def main(argv=None):
 
     make, kw = WORKLOADS[args.workload]
     scene = make()
+    if args.scale != 1.0:
+        kw = dict(kw, width=max(8, int(kw["width"] * args.scale)), height=max(8, int(kw["height"] * args.scale)))
     opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=0, **kw)
     W, H = opt.width, opt.height
-    n_streams = args.streams if args.streams > 0 else (1 if world == 1 else 3)
+    # A rank's share of a millisecond frame is too small to keep its GPU busy (ramp-up and tail of small grids), so
+    # consecutive frames alternate over three scene handles and streams.  Scenes whose materials spawn rays get ONE: their
+    # shares run for many milliseconds, and every handle keeps level queues of its own (up to a quarter of the free memory
+    # each, held until the handle is destroyed).
+    spawns = any(scene.materials[m.material].kind in (2, 3) for m in scene.meshes)
+    n_streams = args.streams if args.streams > 0 else (1 if (world == 1 or spawns) else 3)
     tracers = [api.TracerScene(scene) for _ in range(n_streams)]      # calls on one handle serialise: a handle per stream
     tracer = tracers[0]
     stream = torch.cuda.current_stream().cuda_stream
@@ -268,18 +279,27 @@ def main(argv=None):
                    "sharding": ("%d-row bands interleaved over ranks, one all_gather of the %s rows per frame, overlapped with the "
                                 "next frames; consecutive frames alternate over %d streams per rank"
                                 % (BAND_ROWS, "8-bit" if u8 else "float", n_streams)) if world > 1 else "none",
-                   "streams": n_streams, "spinup_frames": spinup,
+                   "streams": n_streams, "spinup_frames": spinup, "scale": args.scale,
                    "verified": bool(args.verify)},
         "ms_per_frame": round(ms_per_step, 4),
     }
 
     if rank == 0:
-        result["roofline"] = roofline(tracer, opt, W, H, dev, stream, args.workload)
+        prof_all, stale = load_profile()
+        if not args.no_roofline:
+            result["roofline"] = roofline(tracer, opt, W, H, dev, stream, args.workload, prof_all.get(args.workload, {}), stale)
         if world == 1 and not args.no_workloads:
-            ms, mr = other_workloads(args.workload, dev)
-            ms[args.workload] = round(ms_per_step, 3); mr[args.workload] = round(value, 1)
-            result["workloads_ms"] = ms
-            result["workloads_mrays"] = mr
+            rows = other_workloads(args.workload, dev, prof_all)
+            head = result.get("roofline")
+            if head:
+                rows[args.workload] = dict(workload_row(args.workload, prof_all.get(args.workload, {}), head["ms_extend"], head["ms_shadow"],
+                                                        head["ms_replay"], head["_counted"]), ms=round(ms_per_step, 3), mrays=round(value, 1))
+            # one flat dictionary per quantity, keyed by workload (every BASELINE configuration on this GPU, this build)
+            for key in ("ms", "mrays", "dominant_kernel", "bound", "frac", "lane_util", "hbm_frac", "hbm_gbps", "nodes_per_ray", "tris_per_ray",
+                        "hbm_over_tree_bytes"):
+                result["workloads_" + key] = {w: r.get(key) for w, r in rows.items()}
+        if result.get("roofline"):
+            result["roofline"].pop("_counted", None)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, opt, ms_per_step)
         print(json.dumps(result), flush=True)
@@ -289,13 +309,65 @@ def main(argv=None):
     return 0
 
 
-def other_workloads(skip, dev):
-    """Frame time and ray rate of every other benchmark configuration on this GPU (outside the timed headline): a
-    warm-up frame, then the mean of a few frames (one for the multi-second 4K field)."""
+def load_profile():
+    """profiles/traffic.json: per-frame hardware-counter totals per workload and kernel (tools/make_traffic_json.py).
+    Returns ({workload: {kernel: {...}}}, stale); the counters are only used when they were collected on exactly the
+    kernel sources of this build (kernel_src_sha) - otherwise ({}, True)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {}, None
+    try:
+        allp = json.load(open(tpath))
+    except Exception:
+        return {}, None
+    if allp.get("kernel_src_sha") != kernel_source_sha():
+        return {}, True
+    return allp.get("workloads", {}), False
+
+
+PEAK_GINST = SIMDS * CLOCK_HZ / ISSUE_CYCLES / 1e9            # G wave-instructions per second: 1228.8
+NODE_BYTES = 48              # what a lane of the pruning traversal fetches of a 64-byte node (references packed into the planes)
+TRI_BYTES = 48
+
+
+def workload_row(name, prof, ms_ext, ms_sha, ms_replay, cs):
+    """The dominant kernel of one workload's frame against the roofs.  ms_*: live per-frame kernel times (HIP events the
+    library records on the call's stream, summed over the levels and bands of the frame); cs: statistics of a counted
+    frame (nodes fetched, triangles tested); prof: the workload's entry of profiles/traffic.json ({} when stale)."""
+    if ms_sha >= ms_ext:
+        key, ms, rays, nn, nt = "k_shadow", ms_sha, cs.rays_any, cs.nodes_shadow, cs.tris_shadow
+    else:
+        key, ms, rays, nn, nt = "k_extend", ms_ext, cs.rays_closest, cs.nodes_extend, cs.tris_extend
+    if ms_replay > ms:
+        key, ms, rays, nn, nt = "replay", ms_replay, 0, 0, 0
+    k = prof.get(key) or prof.get("k_replay") or prof.get("k_shade") or {} if key == "replay" else prof.get(key, {})
+    row = {"dominant_kernel": key, "ms_dominant": round(ms, 4)}
+    insts, hbm = k.get("valu_insts"), k.get("hbm_bytes")
+    frac = insts / (ms * 1e-3) / 1e9 / PEAK_GINST if insts and ms > 0 else None
+    hbm_gbps = hbm / (ms * 1e-3) / 1e9 if hbm and ms > 0 else None
+    hbm_frac = hbm_gbps / HBM_PEAK_GBS if hbm_gbps else None
+    row["frac"] = round(frac, 4) if frac else None
+    row["hbm_frac"] = round(hbm_frac, 4) if hbm_frac else None
+    row["hbm_gbps"] = round(hbm_gbps, 1) if hbm_gbps else None
+    row["lane_util"] = k.get("lane_utilisation")
+    # which roof is nearer: instruction issue of the vector ALUs, or HBM
+    row["bound"] = None if frac is None or hbm_frac is None else ("hbm" if hbm_frac > frac else "valu_issue")
+    row["nodes_per_ray"] = round(nn / rays, 2) if rays else None
+    row["tris_per_ray"] = round(nt / rays, 2) if rays else None
+    tree_bytes = NODE_BYTES * nn + TRI_BYTES * nt
+    # measured HBM bytes over the bytes of tree the kernel asks for: far below 1 = the tree is served by the caches
+    row["hbm_over_tree_bytes"] = round(hbm / tree_bytes, 4) if (hbm and tree_bytes) else None
+    return row
+
+
+def other_workloads(skip, dev, prof_all):
+    """Frame time, ray rate and roofline figures of every other benchmark configuration on this GPU (outside the timed
+    headline): a warm-up frame with statistics, the mean of a few frames (one for the multi-second 4K field), and one
+    counted frame (nodes fetched / triangles tested)."""
     import torch
     from raytracer_amd import api
     from raytracer_amd._abi import Options, RT_JITTER_HASH
-    ms, mrays = {}, {}
+    rows = {}
     stream = torch.cuda.current_stream().cuda_stream
     for name in WORKLOAD_NAMES:
         if name == skip:
@@ -315,23 +387,30 @@ def other_workloads(skip, dev):
             tracer.render_rect(opt, 0, 0, opt.width, opt.height, out=out, stats=False, stream=stream)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / frames
-        ms[name] = round(dt * 1e3, 3)
-        mrays[name] = round((st.rays_closest + st.rays_any) / dt / 1e6, 1)
+        _, st = tracer.render_rect(opt, 0, 0, opt.width, opt.height, out=out, stats=True, stream=stream)   # per-kernel times, GPU at speed
+        copt = Options.from_buffer_copy(opt)
+        copt.count_traversal = 1
+        _, cs = tracer.render_rect(copt, 0, 0, opt.width, opt.height, out=out, stats=True, stream=stream)
+        row = workload_row(name, prof_all.get(name, {}), st.ms_extend, st.ms_shadow, st.ms_shade, cs)
+        row["ms"] = round(dt * 1e3, 3)
+        row["mrays"] = round((st.rays_closest + st.rays_any) / dt / 1e6, 1)
+        rows[name] = row
         tracer.close()
         del out
         torch.cuda.empty_cache()
-    return ms, mrays
+    return rows
 
 
-def roofline(tracer, opt, W, H, dev, stream, workload):
-    """The dominant kernel of the frame against the roof that binds it.
+def roofline(tracer, opt, W, H, dev, stream, workload, prof, stale):
+    """The dominant kernel of the timed workload's frame against the roof that binds it.
 
-    The scene's tree (about 1 MB) stays in the L1/L2 caches, so the traversal kernels do not run against HBM: hardware
-    counters show a few per cent of the HBM peak.  What they run against is the rate at which a SIMD can issue vector
-    instructions: `achieved` is wave-level vector instructions per second of the kernel (SQ_INSTS_VALU from the committed
-    counter passes over its launch duration), `peak` one instruction per SIMD per 2 cycles.  Counter values are only
-    used when they were collected on exactly the kernel sources of this build (kernel_src_sha), else those fields are
-    null.  The algorithmic-bytes figure (node and triangle fetches, which the caches serve) is kept for information."""
+    The bunny scene's tree (about 1 MB) stays in the L1/L2 caches, so its traversal kernels do not run against HBM:
+    hardware counters show a few per cent of the HBM peak.  What they run against is the rate at which a SIMD can issue
+    vector instructions: `achieved` is wave-level vector instructions per second of the kernel (SQ_INSTS_VALU per frame
+    from the committed counter passes over its time per frame), `peak` one instruction per SIMD per 2 cycles.  Counter
+    values are only used when they were collected on exactly the kernel sources of this build (kernel_src_sha), else
+    those fields are null.  The algorithmic-bytes figure (node and triangle fetches, which the caches serve) is kept for
+    information.  All per-frame: a frame of the heavier workloads is many launches of each kernel."""
     import numpy as np
     import torch
     from raytracer_amd._abi import Options
@@ -346,58 +425,57 @@ def roofline(tracer, opt, W, H, dev, stream, workload):
     for _ in range(n_spin):
         tracer.render_rect(opt, 0, 0, W, H, out=out, stats=False, stream=stream)
     ext, sha, shade = [], [], []
-    for _ in range(9):
+    for _ in range(9 if cs.ms_total < 200 else 3):
         _, st = tracer.render_rect(opt, 0, 0, W, H, out=out, stats=True, stream=stream)
         ext.append(st.ms_extend); sha.append(st.ms_shadow); shade.append(st.ms_shade)
     ms_ext, ms_sha, ms_shade = float(np.median(ext)), float(np.median(sha)), float(np.median(shade))
-    # algorithmic bytes: 64 B per inner node fetched + 48 B per triangle tested, plus the queue records: a nearest-hit
-    # ray writes normal+t (16 B), triangle (4 B) and, on a hit, the hit point (16 B) after reading 36 B of vertex
-    # normals; one (node, light) item of spr+1 light rays reads triangle + hit point (20 B) and writes its count (4 B)
-    b_ext = cs.rays_closest * (20 + 36 + 16) + 64 * cs.nodes_extend + 48 * cs.tris_extend
-    b_sha = cs.rays_any // (opt.spr + 1) * 24 + 64 * cs.nodes_shadow + 48 * cs.tris_shadow
-    if ms_sha >= ms_ext:
-        key, name, b, ms, rays, nn, nt = "k_shadow", "k_shadow (any-hit light rays)", b_sha, ms_sha, cs.rays_any, cs.nodes_shadow, cs.tris_shadow
+    # algorithmic bytes: NODE_BYTES per inner node fetched (a lane of the pruning traversal reads 48 of a node's 64
+    # bytes) + 48 B per triangle tested, plus the queue records: a nearest-hit ray writes normal+t (16 B), triangle (4 B)
+    # and, on a hit, the hit point (16 B) after reading 36 B of vertex normals; one (node, light) item of spr+1 light rays
+    # reads triangle + hit point (20 B) and writes its count (4 B)
+    b_ext = cs.rays_closest * (20 + 36 + 16) + NODE_BYTES * cs.nodes_extend + TRI_BYTES * cs.tris_extend
+    b_sha = cs.rays_any // (opt.spr + 1) * 24 + NODE_BYTES * cs.nodes_shadow + TRI_BYTES * cs.tris_shadow
+    row = workload_row(workload, prof, ms_ext, ms_sha, ms_shade, cs)
+    key = row["dominant_kernel"]
+    name = {"k_shadow": "k_shadow (any-hit light rays)", "k_extend": "k_extend (nearest hit)", "replay": "replay (colour walk)"}[key]
+    if key == "k_shadow":
+        b, ms, rays, nn, nt = b_sha, ms_sha, cs.rays_any, cs.nodes_shadow, cs.tris_shadow
+    elif key == "k_extend":
+        b, ms, rays, nn, nt = b_ext, ms_ext, cs.rays_closest, cs.nodes_extend, cs.tris_extend
     else:
-        key, name, b, ms, rays, nn, nt = "k_extend", "k_extend (nearest hit)", b_ext, ms_ext, cs.rays_closest, cs.nodes_extend, cs.tris_extend
-    sha_now = kernel_source_sha()
-    prof, stale = {}, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            allp = json.load(open(tpath))
-            prof = allp.get("workloads", {}).get(workload, {})
-            stale = allp.get("kernel_src_sha") != sha_now
-            if stale:
-                prof = {}
-        except Exception:
-            prof = {}
-    k = prof.get(key, {})
+        b, ms, rays, nn, nt = 0, ms_shade, 0, 0, 0
+    k = prof.get(key, {}) if key != "replay" else (prof.get("k_replay") or prof.get("k_shade") or {})
     insts, traffic, util, salu = k.get("valu_insts"), k.get("hbm_bytes"), k.get("lane_utilisation"), k.get("salu_insts")
-    ms_prof = k.get("rocprof_avg_ms")
-    peak = SIMDS * CLOCK_HZ / ISSUE_CYCLES / 1e9            # G wave-instructions per second
-    achieved = insts / (ms * 1e-3) / 1e9 if insts else None
-    out = {"bound": "valu_issue", "kernel": name,
-           "achieved": round(achieved, 1) if achieved else None, "peak": round(peak, 1), "unit": "Gwave-inst/s",
+    bound = row["bound"] or "valu_issue"
+    if bound == "hbm":
+        achieved, peak, unit = row["hbm_gbps"], HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = (insts / (ms * 1e-3) / 1e9 if insts else None), PEAK_GINST, "Gwave-inst/s"
+    res = {"bound": bound, "kernel": name,
+           "achieved": round(achieved, 1) if achieved else None, "peak": round(peak, 1), "unit": unit,
            "frac": round(achieved / peak, 4) if achieved else None,
            "traffic": traffic,
-           "launch_ms": round(ms, 4), "launch_ms_rocprof": ms_prof,
+           "launch_ms": round(ms / max(k.get("launches_per_frame") or 1, 1), 4), "kernel_ms_per_frame": round(ms, 4),
+           "kernel_ms_per_frame_rocprof": k.get("rocprof_ms_per_frame"), "launches_per_frame": k.get("launches_per_frame"),
            "lane_utilisation": util,
-           "useful_lane_frac": round(achieved / peak * util, 4) if (achieved and util) else None,
-           "valu_insts_per_launch": insts, "salu_insts_per_launch": salu,
+           "useful_lane_frac": round(row["frac"] * util, 4) if (row["frac"] and util) else None,
+           "valu_issue_frac": row["frac"], "hbm_frac_measured": row["hbm_frac"],
+           "valu_insts_per_frame": insts, "salu_insts_per_frame": salu, "vmem_rd_insts_per_frame": k.get("vmem_rd_insts"),
            "l1_data_path_busy_frac": k.get("td_busy_frac"), "l1_address_path_busy_frac": k.get("ta_busy_frac"),
-           "l1_accesses_per_launch": k.get("l1_accesses"),
-           "hbm_frac_measured": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-           "hbm_traffic_over_algorithmic_queue_bytes": round(traffic / max(b - 64 * nn - 48 * nt, 1), 3) if traffic else None,
-           "algorithmic_bytes_per_launch": int(b), "algorithmic_GBps_cache_served": round(b / (ms * 1e-3) / 1e9, 1),
-           "rays_per_launch": int(rays), "nodes_per_ray": round(nn / max(rays, 1), 2), "tris_per_ray": round(nt / max(rays, 1), 2),
+           "l1_accesses_per_frame": k.get("l1_accesses"), "l1_hit_rate": k.get("l1_hit_rate_est"), "l2_hit_rate": k.get("l2_hit_rate"),
+           "hbm_traffic_over_algorithmic_queue_bytes": round(traffic / max(b - NODE_BYTES * nn - TRI_BYTES * nt, 1), 3) if (traffic and b) else None,
+           "hbm_traffic_over_tree_bytes": row["hbm_over_tree_bytes"],
+           "algorithmic_bytes_per_frame": int(b), "algorithmic_GBps_cache_served": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+           "rays_per_frame": int(rays), "nodes_per_ray": row["nodes_per_ray"], "tris_per_ray": row["tris_per_ray"],
            "ms_extend": round(ms_ext, 4), "ms_shadow": round(ms_sha, 4), "ms_replay": round(ms_shade, 4),
-           "kernel_src_sha": sha_now, "counters_stale": stale,
-           "note": "valu_issue: SQ_INSTS_VALU of the kernel (profiles/traffic.json, collected on the sources kernel_src_sha names) "
-                   "over its launch time, against 1 wave instruction per SIMD per 2 cycles on 1024 SIMDs at 2.4 GHz; l1_*_busy_frac = "
-                   "TD_TD_BUSY / TA_TA_BUSY over SQ_BUSY_CU_CYCLES (the CUs' vector-memory return and address paths); traffic = HBM "
-                   "bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (reads doubled, gfx950); the tree is cache "
-                   "resident, so algorithmic node/triangle bytes are not HBM traffic"}
-    return out
+           "kernel_src_sha": kernel_source_sha(), "counters_stale": stale, "_counted": cs,
+           "note": "valu_issue: SQ_INSTS_VALU of the kernel per frame (profiles/traffic.json, collected on the sources kernel_src_sha names) "
+                   "over its time per frame (HIP events on the call's stream), against 1 wave instruction per SIMD per 2 cycles on 1024 SIMDs "
+                   "at 2.4 GHz; hbm: measured HBM bytes per frame of the kernel over the same time against 8 TB/s; bound = the nearer of the "
+                   "two roofs; l1_*_busy_frac = TD_TD_BUSY / TA_TA_BUSY over SQ_BUSY_CU_CYCLES (the CUs' vector-memory return and address "
+                   "paths); traffic = HBM bytes per frame from separate FETCH_SIZE / WRITE_SIZE passes (reads doubled, gfx950); where the "
+                   "tree is cache resident the algorithmic node/triangle bytes are not HBM traffic (hbm_traffic_over_tree_bytes)"}
+    return res
 
 
 def cpu_baseline(scene, opt, gpu_ms):

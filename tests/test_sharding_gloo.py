@@ -116,3 +116,27 @@ def test_two_ranks_render_and_gather_the_real_frame_on_one_gpu():
         assert r.returncode == 0, r.stderr[-3000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and line["config"]["verified"] is True and line["config"]["rays_per_frame"] == 30050272
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,streams", [("mirror_room", 0), ("mirror_room", 3), ("glass_balls", 0)])
+def test_two_ranks_share_a_frame_of_a_scene_that_spawns_rays(workload, streams):
+    """The same rehearsal on the workloads whose frames are NOT one asynchronous level: mirrors and glass make every rank
+    go through its interleaved share level by level (a host round trip per level, children spawned into the next level's
+    queues, the colour walk over the stored tree), at a third of the frame's size.  With the default one handle per rank
+    and with three handles on three streams per rank; every rank compares the gathered frame with the whole frame."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_WATCHDOG="150")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--verify", "--steps", "4", "--warmup", "1", "--workload", workload,
+           "--scale", "0.34", "--no-cpu-baseline", "--no-workloads", "--no-roofline"]
+    if streams:
+        cmd += ["--streams", str(streams)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["verified"] is True and line["config"]["scale"] == 0.34
+    assert line["config"]["streams"] == (streams or 1)
+    assert line["config"]["rays_per_frame"] > 50_000_000

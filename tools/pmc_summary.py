@@ -1,4 +1,5 @@
-"""Per-kernel means of the counters collected by tools/pmc_profile.sh, plus a few derived ratios."""
+"""Per-kernel, per-launch means of the counters collected by tools/pmc_profile.sh, plus a few derived ratios
+(tools/make_traffic_json.py turns the same files into per-frame totals)."""
 import collections
 import csv
 import glob
@@ -22,9 +23,10 @@ for k, c in sorted(out.items()):
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
         d["lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
     if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
-        # vector instructions issued over what 1024 SIMDs can issue in the kernel's active cycles (one wave64 instruction
-        # per SIMD per 2 cycles); SQ_BUSY_CYCLES is summed over shader engines and is no denominator for this
-        d["valu_issue_frac"] = g("SQ_INSTS_VALU") / (1024 * g("GRBM_GUI_ACTIVE") / 2.0)
+        # vector instructions issued over what the SIMDs can issue in the kernel's active cycles (one wave64 instruction per
+        # SIMD per 2 cycles).  GRBM_GUI_ACTIVE arrives summed over the eight XCDs, each with 128 SIMDs; SQ_BUSY_CYCLES is
+        # summed over shader engines and is no denominator for this
+        d["valu_issue_frac"] = g("SQ_INSTS_VALU") / (128 * g("GRBM_GUI_ACTIVE") / 2.0)
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
         d["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
