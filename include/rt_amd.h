@@ -270,6 +270,34 @@ int rt_save_jpeg(const char* path, const uint8_t* rgb, int width, int height, in
 int rt_encode_jpeg(const uint8_t* rgb, int width, int height, int quality, const char* comment, uint8_t* out,
                    int64_t out_cap, int64_t* out_size);
 
+/* ---- host side: scene files and option files (no device work, usable without a GPU) ----------------------------------
+ *
+ * Replaces load_scene (src/main.cpp:256-395; node transforms retrieve_node_gtrans :240-253; material by name
+ * :331-349 with the constructors' defaults src/materials.cpp:10-118; lights src/lights.cpp:7-25 with the direction
+ * negated as :369 does; camera basis src/cameras.cpp:3-18), which imports through Assimp.  This library reads the
+ * reference's scene format - binary FBX - itself (node records, deflated arrays, connections, the FBX node transform,
+ * polygons fan-triangulated in face order, smooth normals where a mesh brings none) and hands back exactly the arrays
+ * rt_scene_create takes: world-space triangles with corner normals per mesh, materials, lights, one camera.  It also
+ * reads the flat ".rtscene" form (8 bytes "RTSCN01\0", uint32 counts {meshes, materials, lights}, then the C-ABI structs
+ * themselves: camera, materials, lights, and per mesh a 32-byte name, int32 material, int32 n_tris, positions, normals).
+ * The arrays belong to the handle and stay valid until rt_host_scene_free.  Errors: rt_host_last_error(). */
+typedef struct rt_host_scene rt_host_scene;
+int rt_host_scene_load(const char* path, rt_host_scene** out);
+int rt_host_scene_desc(const rt_host_scene* scene, const rt_mesh_desc** meshes, int* n_meshes,
+                       const rt_material_desc** materials, int* n_materials,
+                       const rt_light_desc** lights, int* n_lights, const rt_camera_desc** camera);
+int rt_host_scene_free(rt_host_scene* scene);
+const char* rt_host_last_error(void);
+
+/* The reference's option defaults (src/main.cpp:74-75,103-115: 960x540, -hfov 54.43, -spp 2, -spr 4, -bounce 3,
+ * -rbounce 3, -eps 0.0001, -reps 0.1) with hash jitter, seed 1, and the pruning traversal. */
+int rt_options_default(rt_options* opt);
+/* Replaces read_cmd_tokens (src/main.cpp:646-683) for one line "-key value" of an option file; keys -dispw -disph -hfov
+ * -spp -bounce -spr -eps -reps -rbounce, and -mpbs (the display block size, a host matter: *display_block, may be NULL).
+ * Returns 1 if the line set something, 0 if it was ignored (unknown key, no value, blank - the reference crashes on a
+ * blank line, src/main.cpp:654). */
+int rt_options_parse_line(rt_options* opt, const char* line, int* display_block);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 _LIB = None
 
 EXPORTS = ["rt_init", "rt_last_error", "rt_scene_create", "rt_scene_create_ex", "rt_scene_check_tree", "rt_scene_destroy", "rt_scene_info", "rt_scene_set_level_limit", "rt_tree_check", "rt_trace",
-           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_render_frame_multi", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg"]
+           "rt_trace_counted", "rt_render_rect", "rt_render_rect_noalloc", "rt_render_frame_multi", "rt_resolve_u8", "rt_save_jpeg", "rt_encode_jpeg",
+           "rt_host_scene_load", "rt_host_scene_desc", "rt_host_scene_free", "rt_host_last_error", "rt_options_default", "rt_options_parse_line"]
 
 
 class RtError(RuntimeError):
@@ -62,6 +63,13 @@ def lib():
         L.rt_resolve_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rt_save_jpeg.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.c_char_p]
         L.rt_encode_jpeg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, i64, C.POINTER(i64)]
+        L.rt_host_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.rt_host_scene_desc.argtypes = [vp, C.POINTER(C.POINTER(MeshDesc)), C.POINTER(C.c_int), C.POINTER(C.POINTER(MaterialDesc)), C.POINTER(C.c_int),
+                                         C.POINTER(C.POINTER(LightDesc)), C.POINTER(C.c_int), C.POINTER(C.POINTER(CameraDesc))]
+        L.rt_host_scene_free.argtypes = [vp]
+        L.rt_host_last_error.restype = C.c_char_p
+        L.rt_options_default.argtypes = [C.POINTER(Options)]
+        L.rt_options_parse_line.argtypes = [C.POINTER(Options), C.c_char_p, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -194,6 +202,34 @@ def resolve_u8(rgb, out=None, stream=None):
         out = np.empty((h, w, 3), np.uint8)
     _check(lib().rt_resolve_u8(_ptr(rgb), w, h, _ptr(out), stream), "rt_resolve_u8")
     return out
+
+
+def load_scene_file(path):
+    """A scene file through the library's own loader (rt_host_scene_load: binary FBX as the reference's load_scene reads it,
+    src/main.cpp:256-395, or .rtscene) as a raytracer_amd.scene.Scene.  Host-only, needs no GPU."""
+    from .scene import Camera, Light, Material, Mesh, Scene
+    L = lib()
+    h = C.c_void_p()
+    if L.rt_host_scene_load(str(path).encode(), C.byref(h)) != 0:
+        raise RtError("rt_host_scene_load failed: %s" % L.rt_host_last_error().decode())
+    try:
+        pm, pmat, pl, pc = C.POINTER(MeshDesc)(), C.POINTER(MaterialDesc)(), C.POINTER(LightDesc)(), C.POINTER(CameraDesc)()
+        nm, nmat, nl = C.c_int(), C.c_int(), C.c_int()
+        L.rt_host_scene_desc(h, C.byref(pm), C.byref(nm), C.byref(pmat), C.byref(nmat), C.byref(pl), C.byref(nl), C.byref(pc))
+        f3 = lambda a: np.array(list(a), np.float32)
+        mats = [Material(pmat[i].kind, f3(pmat[i].base), f3(pmat[i].ambient), f3(pmat[i].spec), f3(pmat[i].transp), pmat[i].shininess,
+                         pmat[i].reflectivity, pmat[i].refractivity) for i in range(nmat.value)]
+        lights = [Light(pl[i].kind, f3(pl[i].vec), f3(pl[i].color)) for i in range(nl.value)]
+        cam = Camera(f3(pc[0].pos), f3(pc[0].up), f3(pc[0].w), f3(pc[0].side), pc[0].near_clip, pc[0].far_clip)
+        meshes = []
+        for i in range(nm.value):
+            n = pm[i].n_tris
+            pos = np.ctypeslib.as_array(C.cast(pm[i].pos, C.POINTER(C.c_float)), (n, 3, 3)).copy() if n else np.zeros((0, 3, 3), np.float32)
+            nrm = np.ctypeslib.as_array(C.cast(pm[i].nrm, C.POINTER(C.c_float)), (n, 3, 3)).copy() if n else np.zeros((0, 3, 3), np.float32)
+            meshes.append(Mesh(pm[i].name.decode(), pm[i].material, pos, nrm))
+        return Scene(meshes, mats, lights, cam)
+    finally:
+        L.rt_host_scene_free(h)
 
 
 def save_jpeg(path, img_u8, quality=90, comment="Render Result"):
