@@ -352,6 +352,8 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_done, hipEventDisableTiming);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, hipGetErrorString(e)); }
     sc->d.fault = sc->d_fault; sc->d_fast.fault = sc->d_fault;
+    // a stack never holds more entries than its tree has levels: such a tree takes the kernels whose stack is LDS only
+    sc->d.shallow = 0; sc->d_fast.shallow = (sc->fast_depth <= RT_LDS_SLOTS && !getenv("RT_AMD_DEBUG_DEEP_STACK")) ? 1 : 0;
     *out = sc;
     return RT_OK;
     RT_API_END("rt_scene_create")

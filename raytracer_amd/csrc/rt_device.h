@@ -81,6 +81,7 @@ struct DScene {
     const Material* mats;      // per material
     const int32_t* mesh_mat;   // mesh index -> material index
     uint32_t* fault;           // one word, set to 1 by a lane whose traversal stack overflowed
+    int32_t shallow;           // the tree is no deeper than RT_LDS_SLOTS: its traversal stack never leaves LDS (see StackT)
     Light lights[8];
     int32_t n_lights;
     Camera cam;
@@ -320,12 +321,18 @@ RT_HD float entry_limit(float t0) { return fmaxf(t0 * 0.99999f, 0.f); }
 // [slot][lane of the workgroup] so that a wave's access to one slot is conflict-free; the rest spill to a private
 // array.  Near-first descent rarely holds more than a handful of entries.  The struct holds only scalars (the spill
 // array is a separate object) so that it stays in registers.
-struct StackLds {
+// DEEP == false: for trees no deeper than RT_LDS_SLOTS (a stack never holds more entries than its tree has levels; the
+// host checks the depth when it picks the kernel).  Push and pop are then one LDS access each - without the tiers, their
+// nested branches around every push and pop, and the private array: 1 - 3 % of every frame whose scene has such a tree
+// (the surface-area-heuristic trees of all the smaller scenes: bunny 15 levels, mirror room 16, glass balls 14).
+template <bool DEEP>
+struct StackT {
     RT_LDS_PTR int32_t* lds; // this lane's column: slot s is lds[s * RT_BLOCK]
     int32_t* spill;          // RT_STACK - RT_LDS_SLOTS entries
     uint32_t* fault;         // where an overflow is reported (the scene's fault word; the same for every lane)
     int sp;
     RT_HDM void push(int32_t v) {
+        if (!DEEP) { lds[sp * RT_BLOCK] = v; ++sp; return; }
         if (sp < RT_LDS_SLOTS) lds[sp * RT_BLOCK] = v;
         else if (sp < RT_STACK) spill[sp - RT_LDS_SLOTS] = v;
         else { *fault = 1u; return; }   // the subtree is lost and sp stays put, so every pop stays inside the arrays; the
@@ -335,9 +342,11 @@ struct StackLds {
     }
     RT_HDM int32_t pop() {
         --sp;
+        if (!DEEP) return lds[sp * RT_BLOCK];
         return (sp < RT_LDS_SLOTS) ? lds[sp * RT_BLOCK] : spill[sp - RT_LDS_SLOTS];
     }
 };
+typedef StackT<true> StackLds;
 
 // One triangle against the ray: the reference's Cramer's-rule test (src/geometry.cpp:268-295, same names, same
 // operation order).  Its three true divisions are the expensive part, so each quotient is first estimated with
@@ -384,9 +393,9 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
 // One inner node: tests both children and returns the next reference to visit (the far child is pushed when both are
 // hit; RT_NONE when the stack is empty).  The sixteen node words are passed as scalars so that the same code serves
 // words held in vector registers and words held in scalar registers (a node the whole wave fetched once).
-template <bool EXACT, int OCT, bool ORDER>
+template <bool EXACT, int OCT, bool ORDER, class ST>
 RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8,
-                        float b9, float b10, float b11, int32_t r0, int32_t r1, int32_t r2, int32_t r3, StackLds& st,
+                        float b9, float b10, float b11, int32_t r0, int32_t r1, int32_t r2, int32_t r3, ST& st,
                         V3 o, V3 d, const SlabRay& rd, float lo, float lim) {
     const float lb[6] = {b0, b1, b2, b3, b4, b5};
     const float rb[6] = {b6, b7, b8, b9, b10, b11};
@@ -415,8 +424,8 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
 // best t so far are skipped and the nearer child is visited first.
 // Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
 // so that the lanes of a wave run the same kind of work together.
-template <bool ANY, bool EXACT, int OCT>
-RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRay& rd, float t0, float t1, HitRec& best,
+template <bool ANY, bool EXACT, int OCT, class ST>
+RT_HD bool traverse_oct(const DScene& sc, ST& st, V3 o, V3 d, const SlabRay& rd, float t0, float t1, HitRec& best,
                         uint32_t* n_nodes, uint32_t* n_tris) {
     // the empty record loses no tie: a triangle that passes the test with t = +inf (a ray parallel to it through one
     // of its edges: 0/0 barycentrics pass every comparison) is not a hit - the reference's get_hit keeps a record only
@@ -467,8 +476,8 @@ RT_HD bool traverse_oct(const DScene& sc, StackLds& st, V3 o, V3 d, const SlabRa
 }
 
 // Picks the traversal specialised for the wave's direction octant (see slab_fast).
-template <bool ANY, bool EXACT>
-RT_HD bool traverse(const DScene& sc, StackLds& st, V3 o, V3 d, float t0, float t1, HitRec& best,
+template <bool ANY, bool EXACT, class ST>
+RT_HD bool traverse(const DScene& sc, ST& st, V3 o, V3 d, float t0, float t1, HitRec& best,
                     uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     SlabRay rd; rd.rd = rd.en = rd.ef = v3(0, 0, 0);
     if (EXACT) return traverse_oct<ANY, true, 8>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);

@@ -179,8 +179,8 @@ RT_HD bool light_is_idle(const DScene& sc, const RenderParams& P, const Material
 }
 
 // returns the number of children this node will spawn
-template <bool EXACT>
-RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, StackLds& st, int64_t i,
+template <bool EXACT, class ST>
+RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, ST& st, int64_t i,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     const NodeIn in = node_in(sc, P, L, i);
     HitRec h;
@@ -273,8 +273,8 @@ RT_HD void store_unocc(const DScene& sc, const RenderParams& P, const Level& L, 
 }
 
 // ray k of the item (k < spr: jittered copy, k == spr: the exact direction); true when it reaches the light
-template <bool EXACT>
-RT_HD bool shadow_ray(const DScene& sc, const RenderParams& P, const ShadowItem& it, StackLds& st, int k,
+template <bool EXACT, class ST>
+RT_HD bool shadow_ray(const DScene& sc, const RenderParams& P, const ShadowItem& it, ST& st, int k,
                       uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
     const V3 d = (k < P.spr) ? split_dir(it.exact, P.ray_eps, P, it.key, SITE_SH_SPLIT, (uint32_t)it.li, (uint32_t)k) : it.exact;
     HitRec h;

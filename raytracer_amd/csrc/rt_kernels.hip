@@ -14,6 +14,12 @@ constexpr int BLOCK = RT_BLOCK;
     int32_t stack_spill_[RT_STACK - RT_LDS_SLOTS];                                    \
     StackLds st;                                                                      \
     st.lds = (RT_LDS_PTR int32_t*)lds_stack_ + threadIdx.x; st.spill = stack_spill_; st.fault = sc.fault; st.sp = 0
+// the same for a tree no deeper than RT_LDS_SLOTS (DEEP == false: no private part)
+#define RT_DECLARE_STACK_T(st, DEEP)                                                  \
+    __shared__ int32_t lds_stack_[RT_LDS_SLOTS * BLOCK];                              \
+    int32_t stack_spill_[DEEP ? RT_STACK - RT_LDS_SLOTS : 1];                         \
+    StackT<DEEP> st;                                                                  \
+    st.lds = (RT_LDS_PTR int32_t*)lds_stack_ + threadIdx.x; st.spill = stack_spill_; st.fault = sc.fault; st.sp = 0
 
 // Sum over the 64 lanes, the same value returned to every lane.  Lane-to-lane adds inside the vector ALU (a running sum
 // along each row of 16 lanes, then the row totals carried into the following rows) instead of six exchanges through the
@@ -50,11 +56,11 @@ __device__ __forceinline__ void add_work(unsigned long long* work, uint32_t nn, 
     }
 }
 
-template <bool EXACT, bool COUNT>
+template <bool EXACT, bool COUNT, bool DEEP = true>
 __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work) {
     const int64_t i = (int64_t)xcd_block() * BLOCK + threadIdx.x;
     uint32_t kids = 0, nn = 0, nt = 0;
-    RT_DECLARE_STACK(st);
+    RT_DECLARE_STACK_T(st, DEEP);
     if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
     if (!P.can_spawn) { add_work<COUNT>(work, nn, nt); return; }     // no material of the scene spawns rays: nothing to count
     kids = wave_sum(kids);
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Lev
 // leaves the remaining lanes idle), so the lanes of a wave trace rays of few neighbouring origins and the wave is done
 // when its slowest ray is - a lane that looped over the item's rays would wait for the slowest lane once per ray.
 // The item's count is the population count of the wave's "reached the light" mask over the item's lanes.
-template <bool EXACT, bool COUNT>
+template <bool EXACT, bool COUNT, bool DEEP = true>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, FastDiv div_nodes, uint32_t n_nodes, unsigned long long* traced, unsigned long long* work) {
     const int R = P.spr + 1, per_wave = 64 / R;
     const int lane = threadIdx.x & 63;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     const int64_t w = (int64_t)((uint32_t)v - light * n_nodes) * sc.n_lights + light;
     uint32_t did = 0, nn = 0, nt = 0;
     bool reached = false;
-    RT_DECLARE_STACK(st);
+    RT_DECLARE_STACK_T(st, DEEP);
     ShadowItem it;
     it.idle = false;
     const bool item = sub < per_wave && v < n_items;
@@ -252,6 +258,7 @@ void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Le
         else k_extend<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
     } else {
         if (exact) k_extend<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
+        else if (sc.shallow) k_extend<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
         else k_extend<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
     }
 }
@@ -267,6 +274,7 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
         else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);
     } else {
         if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
+        else if (sc.shallow) k_shadow<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
         else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
     }
 }

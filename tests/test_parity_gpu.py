@@ -709,6 +709,26 @@ def test_failed_device_build_falls_back_to_the_host_builder(oracle_mod, monkeypa
         assert same.mean() >= 0.9999 and bits_equal(tg[same], to[same]).all()
 
 
+def test_shallow_trees_take_the_lds_only_stack_and_change_nothing(monkeypatch):
+    """Scenes whose pruning-traversal tree is no deeper than the LDS part of the traversal stack run kernels without
+    the private-memory tier (every benchmark scene but the 10 M-triangle field).  The same scene created with
+    RT_AMD_DEBUG_DEEP_STACK=1 takes the general kernels: frames and ray counts must be identical, and the depth the
+    choice rests on is the depth of the tree as downloaded and re-walked."""
+    for make, kw in ((lambda: scenes.bunny(phong_surroundings=True), dict(width=160, height=90, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3)),
+                     (lambda: scenes.glass_balls(10), dict(width=96, height=54, hfov=54.5, spp=2, spr=4, max_bounce=3, max_refrac_bounce=5, eps=1e-3))):
+        sc = make()
+        shallow = api.TracerScene(sc)
+        assert shallow.check_tree()["depth"] <= 16
+        monkeypatch.setenv("RT_AMD_DEBUG_DEEP_STACK", "1")
+        deep = api.TracerScene(sc)
+        monkeypatch.delenv("RT_AMD_DEBUG_DEEP_STACK")
+        opt = Options(jitter_mode=RT_JITTER_HASH, seed=3, exact_boxes=0, **kw)
+        a, sa = shallow.render_rect(opt, 0, 0, opt.width, opt.height)
+        b, sb = deep.render_rect(opt, 0, 0, opt.width, opt.height)
+        assert bits_equal(a, b).all()
+        assert (sa.rays_closest, sa.rays_any, sa.ref_get_hit_calls) == (sb.rays_closest, sb.rays_any, sb.ref_get_hit_calls)
+
+
 def test_calls_on_one_handle_from_two_streams_do_not_race():
     """Asynchronous calls on ONE scene handle from different streams share the handle's queues: each call's stream first
     waits for the previous call's work (an event recorded at its end), so back-to-back frames with different options
