@@ -110,8 +110,15 @@ typedef struct rt_options {
     int32_t jitter_mode;        /* RT_JITTER_OFF: every rand() is 100 (no jitter);
                                    RT_JITTER_HASH: counter hash keyed by (seed, pixel, sample, ray path, call site) */
     uint32_t seed;
-    int32_t exact_boxes;        /* 1: slab test with IEEE division and no nearest-hit pruning — visits exactly
-                                      the triangles the reference visits; 0: reciprocal multiply + pruning */
+    int32_t exact_boxes;        /* 0: the pruning traversal (reciprocal multiplies, nearest child first, subtrees beyond the best
+                                   hit skipped, a tree of its own); the winner of every ray is checked against the box of the
+                                   REFERENCE's leaf that holds it, with the reference's arithmetic, and a ray whose winner the
+                                   reference would never have looked at is walked a second time - so the answer is the
+                                   reference's own, not merely one that is as near.
+                                   1: the reference's slab arithmetic (IEEE divisions) on the reference's tree without pruning -
+                                   visits exactly the triangles the reference visits; several times slower.
+                                   2: the pruning traversal without that check (2 - 4 % faster; a few pixels per million can
+                                   then show a hit the reference loses between two of its boxes) */
     int32_t count_traversal;    /* 1: also count inner nodes fetched and triangles tested per kernel kind into
                                    rt_stats (slower kernels; for traffic accounting, not for timing) */
     int32_t row_stride;         /* 0 or 1: rows are image rows.  N > 1: the rows given to rt_render_rect are LOCAL rows of
@@ -147,7 +154,10 @@ typedef struct rt_stats {
     float ms_shadow;            /* any-hit kernels */
     float ms_shade;             /* shade / spawn / resolve kernels */
     int32_t levels;             /* bounce levels processed */
-    int32_t reserved_[3];
+    int32_t reserved_[3];       /* [1], [2]: nearest-hit / light rays that were walked a second time because their first answer
+                                   was a triangle the reference never looks at (exact_boxes = 0).  [0]: 1 when more rays needed
+                                   that second walk than its queue holds (2^20 per launch) and the call was therefore run again
+                                   with exact_boxes = 1 - the same frame, more slowly */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;
@@ -210,7 +220,7 @@ int rt_tree_check(const rt_mesh_desc* meshes, int n_meshes, int which, int64_t o
  * org/dir: [n][3] floats, host or device.  t_out[n] = hit distance or +inf; tri_out[n] = global
  * triangle id (mesh order, then face order) or -1; nrm_out[n][3] = interpolated unit normal
  * (may be NULL).  any_hit != 0 answers only "is there a hit" (what src/render_thread.cpp:158 uses):
- * t_out is then 0 (occluded) or +inf and tri_out is 0/-1. */
+ * t_out is then 0 (occluded) or +inf and tri_out is 0/-1.  exact_boxes as in rt_options (0, 1 or 2). */
 int rt_trace(rt_scene* scene, const float* org, const float* dir, float t0, float t1, int64_t n,
              int any_hit, int exact_boxes, float* t_out, int32_t* tri_out, float* nrm_out, void* stream);
 

@@ -79,6 +79,9 @@ struct LevelBuf {
 #endif
 
 enum { RT_N_COUNTERS = 16 + rt::RT_TRACED_SLOTS * rt::RT_TRACED_STRIDE * 2 };   // u32 words of the counter block
+enum { RT_REDO_CAP = 1 << 20, RT_REDO_CAP_FIXED = 1 << 16 };   // entries per list of a scene's redo queues / of the fixed workspace's
+// words of the counter block the redo queues use: count, ticket, running total per kernel kind (rt::RedoQueue)
+enum { RT_W_REDO_EXT = 2, RT_W_REDO_SHA = 3, RT_W_TICKET_EXT = 12, RT_W_TICKET_SHA = 13, RT_W_TOTAL_EXT = 14, RT_W_TOTAL_SHA = 15 };
 
 struct rt_scene {
     int device = 0;
@@ -99,6 +102,9 @@ struct rt_scene {
     float* d_share = nullptr; int64_t share_cap = 0;     // this GPU's rows of a frame rendered by several GPUs
     hipStream_t own_stream = nullptr;                    // rt_render_frame_multi: one stream per scene
     void* d_io = nullptr; int64_t io_cap = 0;  // staging for rt_trace / rt_resolve_u8 host buffers
+    uint32_t redo_cap = 1u << 30;            // RT_AMD_DEBUG_REDO_CAP lowers the entries a redo list takes (tests of the overflow path)
+    void* d_redo = nullptr;                  // lists of the rays the pruning traversal walks twice (rt::RedoQueue): RT_REDO_CAP
+                                             // node numbers (u32), then as many (item, ray) entries (u64)
     uint32_t* d_fault = nullptr;             // set by a kernel whose traversal stack overflowed (cannot happen for a tree
                                              // that passed the depth check; read back by every synchronising call)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..3] per-kernel timing, [4..5] whole call
@@ -327,6 +333,44 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
     }
     sc->built_on_device = on_device;
     rt::launch_pack_refs(const_cast<rt::Node64*>(sc->d_fast.nodes), sc->fast_nodes, nullptr);
+    {
+        // The reference's leaves and their boxes, out of its flattened trees: a leaf hangs in exactly one child slot of
+        // one node, with the box the reference tests before it looks at the leaf's triangles.  The pruning traversal vets
+        // its candidates against these (rt_device.h ref_leaf_box_hit): box table on the device, and every triangle record
+        // of the pruning traversal's tree told the number of its leaf.
+        std::vector<float> boxes;
+        std::vector<int32_t> leaf_of_id(flat.tris.size(), 0);
+        int32_t n_leaf = 0;
+        // (walked from the entry node along the reference's own child references: the refined leaves' subtrees, appended to
+        // the same node array, are not the reference's)
+        std::vector<int32_t> todo{0};
+        while (!todo.empty()) {
+            const rt::Node64& n = flat.nodes[(size_t)todo.back()];
+            todo.pop_back();
+            for (int side = 0; side < 2; ++side) {
+                const int32_t ref = side ? n.rref : n.lref;
+                if (ref == rt::RT_NONE) continue;
+                if (ref >= 0) {
+                    if ((size_t)ref >= flat.nodes.size() || todo.size() > flat.nodes.size()) { rt_scene_destroy(sc); return fail(RT_ERR_INVALID, "internal: node reference out of range"); }
+                    todo.push_back(ref);
+                    continue;
+                }
+                const float* bx = side ? n.rbox : n.lbox;
+                boxes.insert(boxes.end(), bx, bx + 6); boxes.push_back(0.f); boxes.push_back(0.f);
+                const size_t first = (size_t)~ref;
+                if (first >= flat.tris.size()) { rt_scene_destroy(sc); return fail(RT_ERR_INVALID, "internal: leaf reference out of range"); }
+                for (size_t k = first, e = first + (size_t)flat.tris[first].run; k < e && k < flat.tris.size(); ++k) leaf_of_id[(size_t)flat.info[k].id] = n_leaf;
+                ++n_leaf;
+            }
+        }
+        const float* d_boxes = nullptr; const int32_t* d_leaf = nullptr;
+        if ((rc = upload(sc, boxes.data(), boxes.size(), &d_boxes)) != RT_OK || (rc = upload(sc, leaf_of_id.data(), leaf_of_id.size(), &d_leaf)) != RT_OK) {
+            rt_scene_destroy(sc);
+            return rc;
+        }
+        sc->d_fast.leaf_box = reinterpret_cast<const float4*>(d_boxes);
+        rt::launch_set_ref_leaf(const_cast<rt::Tri48*>(sc->d_fast.tris), sc->d_fast.info, d_leaf, (int64_t)flat.tris.size(), nullptr);
+    }
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "packing the tree's references failed"); }
     const rt::DScene fast_ptrs = sc->d_fast;
     sc->d.n_lights = n_lights;
@@ -339,12 +383,15 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
     sc->d.cam.near_clip = camera->near_clip; sc->d.cam.far_clip = camera->far_clip;
     sc->d_fast = sc->d;
     sc->d_fast.nodes = fast_ptrs.nodes; sc->d_fast.tris = fast_ptrs.tris; sc->d_fast.info = fast_ptrs.info; sc->d_fast.nrm = fast_ptrs.nrm;
+    sc->d_fast.leaf_box = fast_ptrs.leaf_box;
     sc->n_lights = n_lights;
     sc->n_tris = (int64_t)flat.tris.size();
     sc->n_inner = (int64_t)flat.nodes.size();
     sc->n_leaves = flat.n_leaves;
     sc->max_depth = flat.max_depth;
     hipError_t e = hipMalloc((void**)&sc->d_counters, RT_N_COUNTERS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(sc->d_counters, 0, RT_N_COUNTERS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&sc->d_redo, (size_t)RT_REDO_CAP * 12);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_fault, 256);
     if (e == hipSuccess) e = hipMemset(sc->d_fault, 0, 256);
     if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_counters, (RT_N_COUNTERS + 16) * sizeof(uint32_t));
@@ -353,6 +400,7 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, hipGetErrorString(e)); }
     sc->d.fault = sc->d_fault; sc->d_fast.fault = sc->d_fault;
     // a stack never holds more entries than its tree has levels: such a tree takes the kernels whose stack is LDS only
+    if (const char* cap = getenv("RT_AMD_DEBUG_REDO_CAP")) sc->redo_cap = (uint32_t)std::max(1, atoi(cap));
     sc->d.shallow = 0; sc->d_fast.shallow = (sc->fast_depth <= RT_LDS_SLOTS && !getenv("RT_AMD_DEBUG_DEEP_STACK")) ? 1 : 0;
     *out = sc;
     return RT_OK;
@@ -464,6 +512,7 @@ int rt_scene_destroy(rt_scene* sc) {
     for (auto& b : sc->lv) free_level(b);
     if (sc->d_counters) (void)hipFree(sc->d_counters);
     if (sc->d_fault) (void)hipFree(sc->d_fault);
+    if (sc->d_redo) (void)hipFree(sc->d_redo);
     if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->h_counters) (void)hipHostFree(sc->h_counters);
     if (sc->d_stage) (void)hipFree(sc->d_stage);
@@ -529,13 +578,22 @@ struct WorkspaceScope {
         if (order && order->done) { if (hipEventRecord(order->done, s) == hipSuccess) order->pending = true; else (void)hipGetLastError(); }
     }
 };
+// Set when a call ends because its redo queue overflowed: the entry points that render then run the call again in the
+// reference-arithmetic mode, whose frame the vetted pruning mode reproduces anyway.
+static thread_local bool g_redo_overflow = false;
 // The scene's fault word, fetched together with other results a call waits for anyway.
 static int check_fault(rt_scene* sc, hipStream_t s) {
     uint32_t* h = sc->h_counters + RT_N_COUNTERS;
     HIP_TRY(hipMemcpyAsync(h, sc->d_fault, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (*h) {
+        const uint32_t what = *h;
         (void)hipMemsetAsync(sc->d_fault, 0, sizeof(uint32_t), s);      // reported once; the next call starts clean
+        if (what == 2u) {
+            g_redo_overflow = true;
+            return fail(RT_ERR_UNSUPPORTED, "more rays needed a second, vetted walk than the redo queue holds (a scene of needles?); "
+                                            "render with exact_boxes = 1");
+        }
         return fail(RT_ERR_UNSUPPORTED, "a traversal stack overflowed: tree deeper than the traversal stack");
     }
     return RT_OK;
@@ -544,6 +602,7 @@ static int check_fault(rt_scene* sc, hipStream_t s) {
 static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0, float t1, int64_t n, int any_hit, int exact,
                       float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* nodes_out, uint32_t* tris_out, void* stream) {
     if (!sc || n < 0 || (n > 0 && (!org || !dir || !t_out))) return fail(RT_ERR_INVALID, "rt_trace: null argument or negative count");
+    if (exact < 0 || exact > 2) return fail(RT_ERR_INVALID, "rt_trace: exact_boxes is 0, 1 or 2");
     if (n == 0) return RT_OK;
     hipStream_t s = (hipStream_t)stream;
     DeviceGuard dg(sc->device);
@@ -569,7 +628,7 @@ static int trace_impl(rt_scene* sc, const float* org, const float* dir, float t0
         d_cn = nodes_out ? (uint32_t*)(base + 11 * n) : nullptr;
         d_ct = tris_out ? (uint32_t*)(base + 12 * n) : nullptr;
     }
-    rt::launch_trace(any_hit != 0, exact != 0, exact ? sc->d : sc->d_fast, d_org, d_dir, t0, t1, n, d_t, d_tri, d_n, d_cn, d_ct, s);
+    rt::launch_trace(any_hit != 0, exact == 1, exact == 0, exact == 1 ? sc->d : sc->d_fast, d_org, d_dir, t0, t1, n, d_t, d_tri, d_n, d_cn, d_ct, s);
     HIP_TRY(hipGetLastError());
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, s));
@@ -617,6 +676,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                 return fail(RT_ERR_INVALID, "rt_render_rect: local rows reach past the image");
         }
     } else if (y1 > o->height) return fail(RT_ERR_INVALID, "rt_render_rect: rectangle outside the image");
+    if (o->exact_boxes < 0 || o->exact_boxes > 2) return fail(RT_ERR_INVALID, "rt_render_rect: exact_boxes is 0, 1 or 2");
     if (o->spp < 1 || o->spp > 16 || o->spr < 0 || o->spr > 15 || o->max_bounce < 0 || o->max_bounce > 8 ||
         o->max_refrac_bounce < 0 || o->max_refrac_bounce > 8)
         return fail(RT_ERR_UNSUPPORTED, "rt_render_rect: spp 1..16, spr 0..15, bounce and rbounce 0..8");
@@ -642,7 +702,8 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         const float a = d * tanf(3.1415926f * o->hfov / 360);
         P.fl = -a; P.fr = a; P.ft = a * aspect_ratio; P.fb = -P.ft; P.fd = d;
     }
-    const bool exact = o->exact_boxes != 0;
+    const bool exact = o->exact_boxes == 1;
+    const bool vetted = o->exact_boxes == 0;           // 2: the pruning traversal without the second, vetted walk of suspect rays
     const bool counting = o->count_traversal != 0;
     uint64_t work[4] = {0, 0, 0, 0};
     const int spp2 = o->spp * o->spp;
@@ -654,6 +715,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     uint32_t* d_counters = sc->d_counters;
     const size_t counter_bytes = align_up(RT_N_COUNTERS * sizeof(uint32_t), 256);
     const size_t slot_bytes = 16 + 16 + 4 + (size_t)std::max(nl, 1);           // hit, pos, tri, unocc per level-0 slot
+    const size_t fixed_redo_bytes = (size_t)RT_REDO_CAP_FIXED * 12;
     if (fixed) {
         if (sc->any_spawning_material)
             return fail(RT_ERR_UNSUPPORTED, "rt_render_rect_noalloc: the scene has reflective or refractive materials, whose ray "
@@ -661,7 +723,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         if (!out_dev) return fail(RT_ERR_INVALID, "rt_render_rect_noalloc: rgb_out must be device memory");
         d_counters = (uint32_t*)fixed->base;
         // four arrays, each rounded up to 256 bytes
-        budget = (int64_t)((fixed->bytes - counter_bytes - 4 * 256) / slot_bytes);
+        budget = (int64_t)((fixed->bytes - counter_bytes - fixed_redo_bytes - 4 * 256) / slot_bytes);
         const int64_t min_band = (int64_t)((rw + 3) / 4) * 16 * spp2;           // one row of 4x4-pixel tiles
         if (min_band > budget)
             return fail(RT_ERR_UNSUPPORTED, "rt_render_rect_noalloc: rectangle too wide for the fixed workspace (" +
@@ -706,6 +768,16 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
     // a scene none of whose materials spawns rays has one level and its kernels never touch the counters unless
     // statistics are asked for: such a frame is three launches and nothing else
     const bool single_level_async = !sc->any_spawning_material && !timing;
+    // rays of the pruning traversal whose answer is a triangle the reference never looks at are walked a second time
+    rt::RedoQueue redo{};
+    {
+        unsigned char* lists = fixed ? fixed->base + counter_bytes : (unsigned char*)sc->d_redo;
+        redo.cap = std::min(sc->redo_cap, fixed ? (uint32_t)RT_REDO_CAP_FIXED : (uint32_t)RT_REDO_CAP);
+        redo.count_extend = d_counters + RT_W_REDO_EXT; redo.ticket_extend = d_counters + RT_W_TICKET_EXT; redo.total_extend = d_counters + RT_W_TOTAL_EXT;
+        redo.count_shadow = d_counters + RT_W_REDO_SHA; redo.ticket_shadow = d_counters + RT_W_TICKET_SHA; redo.total_shadow = d_counters + RT_W_TOTAL_SHA;
+        redo.list_extend = (uint32_t*)lists; redo.list_shadow = (unsigned long long*)(lists + (size_t)redo.cap * 4);
+    }
+    uint64_t redone_extend = 0, redone_shadow = 0;
 
     // A band whose deeper levels outgrow the item limit or the memory is started again at half the height: nothing of a
     // band reaches the frame before its replay, and the band's statistics are added only once it is through.
@@ -719,7 +791,7 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         int64_t n = (int64_t)((rw + 3) / 4) * ((rows + 3) / 4) * 16 * spp2;   // level-0 slots incl. tile padding
         rt::Level fixed_level{};
         if (fixed) {
-            unsigned char* q = fixed->base + counter_bytes;
+            unsigned char* q = fixed->base + counter_bytes + fixed_redo_bytes;
             fixed_level.implicit = 1;
             fixed_level.hit = (float4*)q; q += align_up((size_t)n * 16, 256);
             fixed_level.pos = (float4*)q; q += align_up((size_t)n * 16, 256);
@@ -738,9 +810,9 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
             if (!single_level_async)
                 HIP_TRY(hipMemsetAsync(d_counters, 0, RT_N_COUNTERS * sizeof(uint32_t), s));
             if (timing) HIP_TRY(hipEventRecord(sc->ev[0], s));
-            rt::launch_extend(exact, D, P, L, n, d_counters, counting ? (unsigned long long*)(d_counters + 4) : nullptr, s);
+            rt::launch_extend(exact, D, P, L, n, d_counters, counting ? (unsigned long long*)(d_counters + 4) : nullptr, vetted ? &redo : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[1], s));
-            rt::launch_shadow(exact, D, P, L, n * nl, d_traced, counting ? (unsigned long long*)(d_counters + 8) : nullptr, s);
+            rt::launch_shadow(exact, D, P, L, n * nl, d_traced, counting ? (unsigned long long*)(d_counters + 8) : nullptr, vetted ? &redo : nullptr, s);
             if (timing) HIP_TRY(hipEventRecord(sc->ev[2], s));
             if (single_level_async) {
                 // the level count is known (one) and the call stays asynchronous
@@ -766,7 +838,9 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                 }
             for (int q = 0; q < 4; ++q) { unsigned long long v; memcpy(&v, sc->h_counters + 4 + 2 * q, 8); b_work[q] += v; }
             int64_t kids = 0;
-            for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) kids += sc->h_counters[rt::RT_KIDS_WORD0 + q * rt::RT_TRACED_STRIDE * 2];
+            // (signed: the second walk of a suspect node corrects slot 0 by the difference in children, which may be negative)
+            for (int q = 0; q < rt::RT_TRACED_SLOTS; ++q) kids += (int32_t)sc->h_counters[rt::RT_KIDS_WORD0 + q * rt::RT_TRACED_STRIDE * 2];
+            redone_extend += sc->h_counters[RT_W_TOTAL_EXT]; redone_shadow += sc->h_counters[RT_W_TOTAL_SHA];
             ++lvl;
             if (kids == 0) break;
             if (lvl >= rt::RT_MAX_LEVELS) return fail(RT_ERR_UNSUPPORTED, "ray tree deeper than the level limit");
@@ -820,9 +894,27 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
         stats->ref_get_hit_calls = 2 * rays_closest + rays_any + rays_idle;
         stats->ms_total = ms_total; stats->ms_extend = ms_extend; stats->ms_shadow = ms_shadow; stats->ms_shade = ms_shade;
         stats->levels = max_levels;
+        stats->reserved_[0] = 0;
+        stats->reserved_[1] = (int32_t)std::min<uint64_t>(redone_extend, INT32_MAX); stats->reserved_[2] = (int32_t)std::min<uint64_t>(redone_shadow, INT32_MAX);
         stats->nodes_extend = work[0]; stats->tris_extend = work[1]; stats->nodes_shadow = work[2]; stats->tris_shadow = work[3];
     }
     return RT_OK;
+}
+
+// A call in the vetted pruning mode that ends because more rays needed the second walk than its queue holds is run
+// again in the reference-arithmetic mode: the same frame and ray counts, more slowly.  (A call that returns without
+// waiting - device output, no statistics - cannot see the overflow; the next call on the handle reports it.)
+static int render_or_fall_back(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream,
+                               const FixedWorkspace* fixed, ScratchOrder* order) {
+    g_redo_overflow = false;
+    int rc = render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, fixed, order);
+    if (rc != RT_OK && g_redo_overflow && o && o->exact_boxes == 0) {
+        rt_options again = *o;
+        again.exact_boxes = 1;
+        rc = render_impl(sc, &again, x0, y0, x1, y1, rgb_out, stats, stream, fixed, order);
+        if (rc == RT_OK && stats) stats->reserved_[0] = 1;       // the call fell back
+    }
+    return rc;
 }
 
 int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, int y1, float* rgb_out, rt_stats* stats, void* stream) {
@@ -830,7 +922,7 @@ int rt_render_rect(rt_scene* sc, const rt_options* o, int x0, int y0, int x1, in
     DeviceGuard dg(sc->device);
     if (!dg.ok) return fail(RT_ERR_HIP, "rt_render_rect: cannot make the scene's device current");
     RT_API_BEGIN
-    return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, nullptr);
+    return render_or_fall_back(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, nullptr, nullptr);
     RT_API_END("rt_render_rect")
 }
 
@@ -844,7 +936,7 @@ int rt_render_rect_noalloc(rt_scene* sc, const rt_options* o, int x0, int y0, in
     if (rc != RT_OK) return rc;
     ScratchOrder* order = &g_scratch_order[sc->device];
     std::lock_guard<std::mutex> use(order->use);        // one call at a time enqueues work on this GPU's workspace
-    return render_impl(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, &fw, order);
+    return render_or_fall_back(sc, o, x0, y0, x1, y1, rgb_out, stats, stream, &fw, order);
     RT_API_END("rt_render_rect_noalloc")
 }
 
@@ -886,7 +978,7 @@ int rt_render_frame_multi(rt_scene* const* scenes, int n_scenes, const rt_option
         if (e != hipSuccess) return bad(RT_ERR_HIP, hipGetErrorString(e));
         rt_options o = *opt;
         o.row_stride = N; o.row_band = band_rows; o.row_phase = i;
-        const int r = render_impl(sc, &o, 0, 0, W, n_local, sc->d_share, stats ? &st[(size_t)i] : nullptr, sc->own_stream, nullptr);
+        const int r = render_or_fall_back(sc, &o, 0, 0, W, n_local, sc->d_share, stats ? &st[(size_t)i] : nullptr, sc->own_stream, nullptr, nullptr);
         if (r != RT_OK) return bad(r, g_err);
         // the bands go straight to their rows of the frame (host memory, or any GPU's: peer copies over the fabric)
         int l = 0;

@@ -82,6 +82,9 @@ struct DScene {
     const int32_t* mesh_mat;   // mesh index -> material index
     uint32_t* fault;           // one word, set to 1 by a lane whose traversal stack overflowed
     int32_t shallow;           // the tree is no deeper than RT_LDS_SLOTS: its traversal stack never leaves LDS (see StackT)
+    const float4* leaf_box;    // pruning traversal's tree only: the boxes of the REFERENCE's leaves, two float4 per leaf
+                               // (lo.xyz hi.x | hi.yz - -); a triangle's leaf number sits in the first spare word of its
+                               // record there (see ref_leaf_box_hit)
     Light lights[8];
     int32_t n_lights;
     Camera cam;
@@ -227,7 +230,8 @@ RT_HD V3 split_dir(V3 exact, float eps, const RenderParams& P, uint32_t node, ui
 }
 
 // ---- traversal ---------------------------------------------------------------------------------------------
-struct HitRec { float t; int32_t tri; int32_t rank; float beta, gamma; };   // tri = position in the triangle array, -1 = none
+struct HitRec { float t; int32_t tri; int32_t rank; float beta, gamma;      // tri = position in the triangle array, -1 = none
+                int32_t leaf; };                                             // pruning traversal: the reference's leaf of the hit triangle
 
 // Slab test of one box with the reference's arithmetic (src/geometry.cpp:25-37: six true divisions, fmin/fmax that
 // drop NaNs).
@@ -348,6 +352,42 @@ struct StackT {
 };
 typedef StackT<true> StackLds;
 
+// Would the reference have looked at this triangle at all?  It tests a triangle iff the box of the leaf that holds it in
+// ITS tree passes ITS slab test (all boxes above contain that box, and the test is monotone in the box, so they pass
+// whenever it does).  The pruning traversal walks another tree with widened boxes and so meets triangles the reference
+// never tests; a few of those pass the Cramer test by rounding (a ray grazing a corner within units in the last place).
+// Checking a candidate against its reference leaf's box with the reference's arithmetic removes them: what the pruning
+// traversal reports is then what the reference reports, not merely something nearer or equal.
+RT_HD bool ref_leaf_box_hit(const DScene& sc, int32_t leaf, V3 o, V3 d) {
+    const float4 b0 = sc.leaf_box[2 * (int64_t)leaf], b1 = sc.leaf_box[2 * (int64_t)leaf + 1];
+    const float b[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y};
+    float tmin;
+    return slab_exact(b, o, d, tmin);
+}
+
+// The same question for the winner of a walk, asked cheaply first: with 1/d at hand the six plane distances are six
+// multiplications, each within 4e-7 of itself of the reference's rounded quotient.  The reference's test asks whether the
+// latest entry is at most the earliest exit; an entry and an exit of ONE axis are ordered by construction, so what decides
+// are the six pairs of different axes - if each holds with 1e-6 of the magnitudes to spare (and the earliest exit is
+// clearly positive), the exact arithmetic agrees and its six divisions are not needed.  Anything else - a ray along a
+// box face, a zero direction component (infinities and NaNs fail every comparison here) - takes the exact test.
+RT_HD bool ref_leaf_box_hit_quick(const DScene& sc, int32_t leaf, V3 o, V3 d, V3 rd) {
+    const float4 b0 = sc.leaf_box[2 * (int64_t)leaf], b1 = sc.leaf_box[2 * (int64_t)leaf + 1];
+    const float x1 = (b0.x - o.x) * rd.x, x2 = (b0.w - o.x) * rd.x;
+    const float y1 = (b0.y - o.y) * rd.y, y2 = (b1.x - o.y) * rd.y;
+    const float z1 = (b0.z - o.z) * rd.z, z2 = (b1.y - o.z) * rd.z;
+    const float nx = fminf(x1, x2), fx = fmaxf(x1, x2), ny = fminf(y1, y2), fy = fmaxf(y1, y2), nz = fminf(z1, z2), fz = fmaxf(z1, z2);
+    const float k = 1e-6f;
+    const bool clear = (int)(fmaf(k, fabsf(nx) + fabsf(fy), nx) <= fy) & (int)(fmaf(k, fabsf(nx) + fabsf(fz), nx) <= fz) &
+                       (int)(fmaf(k, fabsf(ny) + fabsf(fx), ny) <= fx) & (int)(fmaf(k, fabsf(ny) + fabsf(fz), ny) <= fz) &
+                       (int)(fmaf(k, fabsf(nz) + fabsf(fx), nz) <= fx) & (int)(fmaf(k, fabsf(nz) + fabsf(fy), nz) <= fy) &
+                       (int)(fminf(fminf(fx, fy), fz) > 1e-30f);
+    if (clear) return true;
+    const float b[6] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y};
+    float tmin;
+    return slab_exact(b, o, d, tmin);
+}
+
 // One triangle against the ray: the reference's Cramer's-rule test (src/geometry.cpp:268-295, same names, same
 // operation order).  Its three true divisions are the expensive part, so each quotient is first estimated with
 // the hardware reciprocal (relative error of a few units in the last place): a triangle whose estimate is outside
@@ -424,14 +464,14 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
 // best t so far are skipped and the nearer child is visited first.
 // Shape: an inner loop that only descends through inner nodes and an inner loop that only tests a leaf's triangles,
 // so that the lanes of a wave run the same kind of work together.
-template <bool ANY, bool EXACT, int OCT, class ST>
+template <bool ANY, bool EXACT, int OCT, bool VET, class ST>
 RT_HD bool traverse_oct(const DScene& sc, ST& st, V3 o, V3 d, const SlabRay& rd, float t0, float t1, HitRec& best,
                         uint32_t* n_nodes, uint32_t* n_tris) {
     // the empty record loses no tie: a triangle that passes the test with t = +inf (a ray parallel to it through one
     // of its edges: 0/0 barycentrics pass every comparison) is not a hit - the reference's get_hit keeps a record only
     // if its t is BELOW the initial INFINITY (src/render_thread.cpp:8,15)
-    best.t = INFINITY; best.tri = -1; best.rank = INT32_MIN; best.beta = 0.f; best.gamma = 0.f;
     const float lo = entry_limit(t0);
+    best.t = INFINITY; best.tri = -1; best.rank = INT32_MIN; best.beta = 0.f; best.gamma = 0.f; best.leaf = 0;
     st.sp = 0;
     int32_t cur = 0;
     bool found = false;
@@ -455,13 +495,17 @@ RT_HD bool traverse_oct(const DScene& sc, ST& st, V3 o, V3 d, const SlabRay& rd,
                 if (n_tris) RT_COUNT_STEP(*n_tris);
                 float t, beta, gamma;
                 if (!tri_test(p0, p1, p2, o, d, t0, ANY ? t1 : fminf(t1, best.t), t, beta, gamma)) continue;
+                // VET (the rare second walk of a ray, kernels of their own): a candidate of the pruning traversal counts only
+                // if the reference would have looked at it
+                if (VET && !ref_leaf_box_hit(sc, RT_F2I(p0.w), o, d)) continue;
                 // any-hit with the reference's arithmetic on the reference's tree: whatever passes the test occludes, a
                 // NaN t included (0/0: a zero-area triangle, a needle whose determinant cancels to zero on this ray) -
                 // the reference's boolean (src/render_thread.cpp:158).  On the pruning traversal's own tree a NaN t is
                 // no occluder: which rays reach such a triangle depends on the boxes around it.
-                if (ANY) { if (EXACT || t == t) return true; }
+                if (ANY) { if (EXACT || t == t) { best.tri = k; best.leaf = RT_F2I(p0.w); return true; } }
                 else if (t < best.t || (t == best.t && RT_F2I(p2.w) < best.rank)) {
                     best.t = t; best.tri = k; best.rank = RT_F2I(p2.w); best.beta = beta; best.gamma = gamma;
+                    if (!EXACT) best.leaf = RT_F2I(p0.w);
                     found = true;
                 }
                 // passed the test with a t that is +inf or NaN and nothing recorded so far: the reference's get_hit
@@ -476,11 +520,16 @@ RT_HD bool traverse_oct(const DScene& sc, ST& st, V3 o, V3 d, const SlabRay& rd,
 }
 
 // Picks the traversal specialised for the wave's direction octant (see slab_fast).
-template <bool ANY, bool EXACT, class ST>
+// VET == false (the kernels every ray goes through): *suspect is set when the winner (nearest hit) or the occluder (any
+// hit) turns out to be a triangle the reference never looks at - met through the widened boxes of the pruning tree and
+// accepted by rounding; the caller then queues the ray for the kernels with VET == true, which walk it again vetting
+// every candidate on the way and so find the reference's own answer.  (About one ray in a hundred thousand; vetting
+// inside the loop of every ray cost 17 % and a function call from it as much, in registers.)
+template <bool ANY, bool EXACT, class ST, bool VET = false>
 RT_HD bool traverse(const DScene& sc, ST& st, V3 o, V3 d, float t0, float t1, HitRec& best,
-                    uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+                    uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr, bool* suspect = nullptr) {
     SlabRay rd; rd.rd = rd.en = rd.ef = v3(0, 0, 0);
-    if (EXACT) return traverse_oct<ANY, true, 8>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+    if (EXACT) return traverse_oct<ANY, true, 8, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
     bool usable;
     rd = make_slab_ray(o, d, usable);
     int oct = (int)(((uint32_t)RT_F2I(d.x) >> 31) | (((uint32_t)RT_F2I(d.y) >> 31) << 1) | (((uint32_t)RT_F2I(d.z) >> 31) << 2));
@@ -489,17 +538,21 @@ RT_HD bool traverse(const DScene& sc, ST& st, V3 o, V3 d, float t0, float t1, Hi
     if (!usable) oct = 8;
     const int uoct = __builtin_amdgcn_readfirstlane(oct);
     oct = (__builtin_amdgcn_ballot_w64(oct != uoct) == 0) ? uoct : 8;
+    if (VET) return traverse_oct<ANY, false, 8, true>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+    bool found;
     switch (oct) {
-        case 0: return traverse_oct<ANY, false, 0>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 1: return traverse_oct<ANY, false, 1>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 2: return traverse_oct<ANY, false, 2>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 3: return traverse_oct<ANY, false, 3>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 4: return traverse_oct<ANY, false, 4>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 5: return traverse_oct<ANY, false, 5>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 6: return traverse_oct<ANY, false, 6>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        case 7: return traverse_oct<ANY, false, 7>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
-        default: return traverse_oct<ANY, false, 8>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris);
+        case 0: found = traverse_oct<ANY, false, 0, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 1: found = traverse_oct<ANY, false, 1, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 2: found = traverse_oct<ANY, false, 2, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 3: found = traverse_oct<ANY, false, 3, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 4: found = traverse_oct<ANY, false, 4, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 5: found = traverse_oct<ANY, false, 5, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 6: found = traverse_oct<ANY, false, 6, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        case 7: found = traverse_oct<ANY, false, 7, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
+        default: found = traverse_oct<ANY, false, 8, false>(sc, st, o, d, rd, t0, t1, best, n_nodes, n_tris); break;
     }
+    if (suspect && found && !ref_leaf_box_hit_quick(sc, best.leaf, o, d, rd.rd)) *suspect = true;
+    return found;
 }
 
 // src/geometry.cpp:297-306: interpolated unit normal of the hit

@@ -179,15 +179,17 @@ RT_HD bool light_is_idle(const DScene& sc, const RenderParams& P, const Material
 }
 
 // returns the number of children this node will spawn
-template <bool EXACT, class ST>
+// suspect (may be NULL; pruning traversal only): set when the hit is a triangle the reference never looks at - the caller
+// queues the node for the same function with VET == true, which redoes all of the node's results (see traverse)
+template <bool EXACT, class ST, bool VET = false>
 RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, ST& st, int64_t i,
-                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr, bool* suspect = nullptr) {
     const NodeIn in = node_in(sc, P, L, i);
     HitRec h;
     bool hit = false;
     const V3 d = in.d;
     if (meta_type(in.packed) != RAY_NONE)
-        hit = traverse<false, EXACT>(sc, st, in.o, d, P.eps, INFINITY, h, n_nodes, n_tris);
+        hit = traverse<false, EXACT, ST, VET>(sc, st, in.o, d, P.eps, INFINITY, h, n_nodes, n_tris, suspect);
     float r_theta = 0.f;
     int kids = 0, flags = in.packed;
     float4 pk = mk4(v3(0, 0, 0), 0.f), hn = mk4(v3(0, 0, 0), INFINITY);
@@ -272,13 +274,23 @@ RT_HD void store_unocc(const DScene& sc, const RenderParams& P, const Level& L, 
     L.rec[i].unocc[(uint32_t)w - i * (uint32_t)sc.n_lights] = (uint8_t)unocc;
 }
 
+// one more light ray of item w reached its light after all (the second, vetted walk of a suspect ray): the item's count
+// byte + 1, as an atomic on the word that holds it (other lanes may be at its neighbours)
+RT_HD void bump_unocc(const DScene& sc, const RenderParams& P, const Level& L, int64_t w) {
+    uint8_t* p;
+    if (L.implicit) p = L.unocc + w;
+    else { const uint32_t i = fdiv((uint32_t)w, P.div_lights); p = L.rec[i].unocc + ((uint32_t)w - i * (uint32_t)sc.n_lights); }
+    const uintptr_t a = (uintptr_t)p;
+    atomicAdd(reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3), 1u << (8 * (a & 3)));
+}
+
 // ray k of the item (k < spr: jittered copy, k == spr: the exact direction); true when it reaches the light
-template <bool EXACT, class ST>
+template <bool EXACT, class ST, bool VET = false>
 RT_HD bool shadow_ray(const DScene& sc, const RenderParams& P, const ShadowItem& it, ST& st, int k,
-                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr) {
+                      uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr, bool* suspect = nullptr) {
     const V3 d = (k < P.spr) ? split_dir(it.exact, P.ray_eps, P, it.key, SITE_SH_SPLIT, (uint32_t)it.li, (uint32_t)k) : it.exact;
     HitRec h;
-    return !traverse<true, EXACT>(sc, st, it.p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris);
+    return !traverse<true, EXACT, ST, VET>(sc, st, it.p, d, P.eps, sc.cam.far_clip, h, n_nodes, n_tris, suspect);
 }
 
 // ------------------------------------------------------------------------------------------------- spawn
@@ -619,11 +631,14 @@ RT_HD void body_sum(const RenderParams& P, const Level* lv, int64_t pl, float* r
 // ------------------------------------------------------------------------------------------- batch trace
 template <bool ANY, bool EXACT>
 RT_HD void body_trace(const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t i,
-                      float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cnt_nodes, uint32_t* cnt_tris, StackLds& st) {
+                      float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cnt_nodes, uint32_t* cnt_tris, StackLds& st, bool vet) {
     const V3 o = v3p(org + 3 * i), d = v3p(dir + 3 * i);
     HitRec h;
     uint32_t nn = 0, nt = 0;
-    const bool hit = traverse<ANY, EXACT>(sc, st, o, d, t0, t1, h, cnt_nodes ? &nn : nullptr, cnt_tris ? &nt : nullptr);
+    bool suspect = false;
+    bool hit = traverse<ANY, EXACT>(sc, st, o, d, t0, t1, h, cnt_nodes ? &nn : nullptr, cnt_tris ? &nt : nullptr, (EXACT || !vet) ? nullptr : &suspect);
+    // a batch is no hot path: a suspect answer of the pruning traversal is redone at once, every candidate vetted
+    if (!EXACT && suspect) hit = traverse<ANY, false, StackLds, true>(sc, st, o, d, t0, t1, h, cnt_nodes ? &nn : nullptr, cnt_tris ? &nt : nullptr);
     if (ANY) {
         t_out[i] = hit ? 0.f : INFINITY;
         if (tri_out) tri_out[i] = hit ? 0 : -1;

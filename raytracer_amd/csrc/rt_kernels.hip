@@ -56,12 +56,21 @@ __device__ __forceinline__ void add_work(unsigned long long* work, uint32_t nn, 
     }
 }
 
+// appends one entry to a redo list (one atomic per suspect ray: about one ray in a hundred thousand)
+template <class T>
+__device__ __forceinline__ void redo_push(uint32_t* count, T* list, uint32_t cap, T entry, uint32_t* fault) {
+    const uint32_t at = atomicAdd(count, 1u);
+    if (at < cap) list[at] = entry; else *fault = 2u;
+}
+
 template <bool EXACT, bool COUNT, bool DEEP = true>
-__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work) {
+__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work, RedoQueue redo) {
     const int64_t i = (int64_t)xcd_block() * BLOCK + threadIdx.x;
     uint32_t kids = 0, nn = 0, nt = 0;
     RT_DECLARE_STACK_T(st, DEEP);
-    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+    bool suspect = false;
+    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr, (!EXACT && redo.cap) ? &suspect : nullptr);
+    if (!EXACT && suspect) redo_push(redo.count_extend, redo.list_extend, redo.cap, (uint32_t)i, sc.fault);
     if (!P.can_spawn) { add_work<COUNT>(work, nn, nt); return; }     // no material of the scene spawns rays: nothing to count
     kids = wave_sum(kids);
     // one atomic per wave on ONE word would queue up in a single L2 channel (about 8 ns each): 64 words 128 bytes apart
@@ -73,8 +82,43 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Lev
 // leaves the remaining lanes idle), so the lanes of a wave trace rays of few neighbouring origins and the wave is done
 // when its slowest ray is - a lane that looped over the item's rays would wait for the slowest lane once per ray.
 // The item's count is the population count of the wave's "reached the light" mask over the item's lanes.
+// Second walk of the queued nodes, every candidate vetted: all of a node's results are written again, and the level's
+// count of children is corrected by the difference (as a wrapped 32-bit sum: the host adds the slots as signed numbers).
+// A handful of workgroups stride over the list; the last one to finish zeroes count and ticket for the next use.
+constexpr int REDO_BLOCKS = 32;
+template <class F>
+__device__ __forceinline__ void redo_drain(uint32_t* count, uint32_t* ticket, uint32_t* total, uint32_t cap, F&& each) {
+    const uint32_t n = min(*reinterpret_cast<volatile uint32_t*>(count), cap);
+    if (n && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(total, n);      // for the call's statistics
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) each(k);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) { *count = 0u; *ticket = 0u; }
+}
+__global__ __launch_bounds__(BLOCK) void k_extend_redo(DScene sc, RenderParams P, Level L, uint32_t* counters, RedoQueue redo) {
+    RT_DECLARE_STACK(st);
+    redo_drain(redo.count_extend, redo.ticket_extend, redo.total_extend, redo.cap, [&](uint32_t k) {
+        const int64_t i = redo.list_extend[k];
+        const int before = (P.can_spawn && res_tri(L, i) >= 0) ? res_kid_count(L, i) : 0;
+        const int after = body_extend<false, StackLds, true>(sc, P, L, st, i);
+        if (P.can_spawn && after != before) atomicAdd(&counters[RT_KIDS_WORD0], (uint32_t)(after - before));
+    });
+}
+__global__ __launch_bounds__(BLOCK) void k_shadow_redo(DScene sc, RenderParams P, Level L, RedoQueue redo) {
+    RT_DECLARE_STACK(st);
+    redo_drain(redo.count_shadow, redo.ticket_shadow, redo.total_shadow, redo.cap, [&](uint32_t k) {
+        const unsigned long long e = redo.list_shadow[k];
+        const int64_t w = (int64_t)(e >> 4);
+        ShadowItem it;
+        it.idle = false;
+        // the first walk found the ray occluded (by the suspect triangle): if the vetted walk reaches the light, the item's
+        // count is one short
+        if (shadow_item(sc, P, L, w, it) && shadow_ray<false, StackLds, true>(sc, P, it, st, (int)(e & 15))) bump_unocc(sc, P, L, w);
+    });
+}
+
 template <bool EXACT, bool COUNT, bool DEEP = true>
-__global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, FastDiv div_nodes, uint32_t n_nodes, unsigned long long* traced, unsigned long long* work) {
+__global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, FastDiv div_nodes, uint32_t n_nodes, unsigned long long* traced, unsigned long long* work, RedoQueue redo) {
     const int R = P.spr + 1, per_wave = 64 / R;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)xcd_block() * BLOCK + threadIdx.x) >> 6;
@@ -92,7 +136,9 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     const bool item = sub < per_wave && v < n_items;
     if (item && shadow_item(sc, P, L, w, it)) {
         did = 1;
-        reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr);
+        bool suspect = false;
+        reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr, (!EXACT && redo.cap) ? &suspect : nullptr);
+        if (!EXACT && suspect) redo_push(redo.count_shadow, redo.list_shadow, redo.cap, ((unsigned long long)w << 4) | (unsigned long long)k, sc.fault);
     }
     const unsigned long long mask = __ballot(reached);
     if (did && k == 0) store_unocc(sc, P, L, w, (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull)));
@@ -205,10 +251,10 @@ __global__ __launch_bounds__(BLOCK) void k_sum(RenderParams P, LevelSet ls, int6
 
 template <bool ANY, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const float* org, const float* dir, float t0, float t1, int64_t n,
-                                                 float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct) {
+                                                 float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct, int vet) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     RT_DECLARE_STACK(st);
-    if (i < n) body_trace<ANY, EXACT>(sc, org, dir, t0, t1, i, t_out, tri_out, nrm_out, cn, ct, st);
+    if (i < n) body_trace<ANY, EXACT>(sc, org, dir, t0, t1, i, t_out, tri_out, nrm_out, cn, ct, st, vet != 0);
 }
 
 // kernels without a traversal stack or a tail of slow waves keep four waves per workgroup (fewer, fuller workgroups)
@@ -244,39 +290,50 @@ __global__ __launch_bounds__(FLAT_BLOCK) void k_pack_refs(Node64* nodes, int64_t
     nodes[i] = nd;
 }
 
+__global__ __launch_bounds__(FLAT_BLOCK) void k_set_ref_leaf(Tri48* tris, const TriInfo* info, const int32_t* leaf_of_id, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * FLAT_BLOCK + threadIdx.x;
+    if (i < n) tris[i].run = leaf_of_id[info[i].id];
+}
+
 inline unsigned blocks(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 inline unsigned xcd_grid(int64_t n) { return (blocks(n) + 63u) & ~63u; }      // for the kernels that use xcd_block()
 
 }  // namespace
 
 void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n, uint32_t* counters,
-                   unsigned long long* work, hipStream_t s) {
+                   unsigned long long* work, const RedoQueue* redo, hipStream_t s) {
     if (n <= 0) return;
     const unsigned g = xcd_grid(n);
+    RedoQueue q{};
+    if (redo && !exact) q = *redo;
     if (work) {
-        if (exact) k_extend<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
-        else k_extend<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work);
+        if (exact) k_extend<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work, q);
+        else k_extend<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work, q);
     } else {
-        if (exact) k_extend<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
-        else if (sc.shallow) k_extend<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
-        else k_extend<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr);
+        if (exact) k_extend<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
+        else if (sc.shallow) k_extend<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
+        else k_extend<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
     }
+    if (q.cap) k_extend_redo<<<REDO_BLOCKS, BLOCK, 0, s>>>(sc, P, L, counters, q);
 }
 void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Level& L, int64_t n_items, unsigned long long* traced,
-                   unsigned long long* work, hipStream_t s) {
+                   unsigned long long* work, const RedoQueue* redo, hipStream_t s) {
     if (n_items <= 0) return;
     const int64_t per_wave = 64 / (P.spr + 1);
     const unsigned g = xcd_grid((n_items + per_wave - 1) / per_wave * 64);
     const uint32_t n_nodes = (uint32_t)(n_items / std::max(sc.n_lights, 1));
     const FastDiv dn = make_fastdiv(n_nodes);
+    RedoQueue q{};
+    if (redo && !exact) q = *redo;
     if (work) {
-        if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);
-        else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work);
+        if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work, q);
+        else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work, q);
     } else {
-        if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
-        else if (sc.shallow) k_shadow<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
-        else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr);
+        if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
+        else if (sc.shallow) k_shadow<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
+        else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
     }
+    if (q.cap) k_shadow_redo<<<REDO_BLOCKS, BLOCK, 0, s>>>(sc, P, L, q);
 }
 void launch_spawn(const DScene& sc, const RenderParams& P, const Level& L, const Level& N, int64_t n, uint32_t* cursor, hipStream_t s) {
     if (n > 0) k_spawn<<<(unsigned)((n + SPAWN_BLOCK - 1) / SPAWN_BLOCK), SPAWN_BLOCK, 0, s>>>(sc, P, L, N, n, cursor);
@@ -293,17 +350,20 @@ void launch_shade_sum(const DScene& sc, const RenderParams& P, const LevelSet& l
     if (n_nodes0 > 0) k_shade<<<blocks(n_nodes0), BLOCK, 0, s>>>(sc, P, ls, n_nodes0);
     if (n_pixels > 0) k_sum<<<blocks(n_pixels), BLOCK, 0, s>>>(P, ls, n_pixels, rgb_out);
 }
-void launch_trace(bool any, bool exact, const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t n,
+void launch_trace(bool any, bool exact, bool vet, const DScene& sc, const float* org, const float* dir, float t0, float t1, int64_t n,
                   float* t_out, int32_t* tri_out, float* nrm_out, uint32_t* cn, uint32_t* ct, hipStream_t s) {
     if (n <= 0) return;
     const unsigned g = blocks(n);
-    if (any && exact) k_trace<true, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
-    else if (any) k_trace<true, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
-    else if (exact) k_trace<false, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
-    else k_trace<false, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct);
+    if (any && exact) k_trace<true, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct, vet ? 1 : 0);
+    else if (any) k_trace<true, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct, vet ? 1 : 0);
+    else if (exact) k_trace<false, true><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct, vet ? 1 : 0);
+    else k_trace<false, false><<<g, BLOCK, 0, s>>>(sc, org, dir, t0, t1, n, t_out, tri_out, nrm_out, cn, ct, vet ? 1 : 0);
 }
 void launch_pack_refs(Node64* nodes, int64_t n, hipStream_t s) {
     if (n > 0) k_pack_refs<<<(unsigned)((n + FLAT_BLOCK - 1) / FLAT_BLOCK), FLAT_BLOCK, 0, s>>>(nodes, n);
+}
+void launch_set_ref_leaf(Tri48* tris, const TriInfo* info, const int32_t* leaf_of_id, int64_t n, hipStream_t s) {
+    if (n > 0) k_set_ref_leaf<<<(unsigned)((n + FLAT_BLOCK - 1) / FLAT_BLOCK), FLAT_BLOCK, 0, s>>>(tris, info, leaf_of_id, n);
 }
 void launch_resolve_u8(const float* rgb, int W, int H, uint8_t* out, hipStream_t s) {
     const int64_t n = (int64_t)W * H * 3;

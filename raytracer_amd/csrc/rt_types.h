@@ -29,7 +29,9 @@ struct alignas(16) Node64 {
 // 48-byte triangle, traversal order.  Edges are stored pre-subtracted exactly as Triangle::hit forms them
 // (src/geometry.cpp:268-273: a-b and a-c component-wise), so the device arithmetic is the same rounding sequence.
 struct alignas(16) Tri48 {
-    float ax, ay, az;  int32_t run;        // vertex a; run = triangles from this one to the end of the reference's leaf
+    float ax, ay, az;  int32_t run;        // vertex a; run = triangles from this one to the end of the reference's leaf (in the
+                                           // pruning traversal's own copies on the device: the number of the reference's leaf
+                                           // that holds the triangle, see DScene::leaf_box)
     float abx, aby, abz; int32_t run_fine; // a - b; the same for the refined leaves
     float acx, acy, acz; int32_t rank;     // a - c; tie rank: among equal t the reference returns the lowest rank
 };

@@ -3,7 +3,10 @@
 Bars (stated by the project's target): primary-hit triangle ids equal on >= 99.99 % of rays, hit t within 1e-5
 relative, 8-bit pixels within 1.  What is asserted here is stricter wherever the design makes it exact:
   * exact_boxes=1 (the reference's slab arithmetic, no pruning): ids, t and normals BIT-EQUAL to the oracle;
-  * exact_boxes=0 (reciprocal slab test + pruning): ids >= 99.99 % equal, and where the id is equal t and the
+  * exact_boxes=0 (reciprocal slab test + pruning, suspect winners walked again against the reference's leaf boxes):
+    the frame and the rays of exact_boxes=1; against the oracle the looser bar is kept where scenes hold needles,
+    whose far-outside "hits" of the reference's Cramer test no tree of tighter boxes reaches;
+  * exact_boxes=2 (the same without the second walk): ids >= 99.99 % equal, and where the id is equal t and the
     normal are bit-equal (the triangle test is the same arithmetic);
   * float framebuffers: bit-equal for Lambert/Phong scenes (colour arithmetic is replayed in the reference's
     order); within 1e-5 relative for refractive scenes (device expf differs from glibc expf in the last place).
@@ -727,6 +730,67 @@ def test_shallow_trees_take_the_lds_only_stack_and_change_nothing(monkeypatch):
         b, sb = deep.render_rect(opt, 0, 0, opt.width, opt.height)
         assert bits_equal(a, b).all()
         assert (sa.rays_closest, sa.rays_any, sa.ref_get_hit_calls) == (sb.rays_closest, sb.rays_any, sb.ref_get_hit_calls)
+
+
+@pytest.mark.parametrize("name", ["bunny_phong", "mirror_room", "glass_balls", "field"])
+def test_pruning_mode_returns_the_frame_of_the_reference_arithmetic(name, monkeypatch):
+    """exact_boxes = 0, the mode that is timed, must give the frame of exact_boxes = 1 (which the other tests pin to the
+    oracle bit for bit): a ray whose pruning-traversal winner lies in a leaf of the REFERENCE's tree whose box the ray
+    misses under the reference's own slab arithmetic (src/AABBTree.cpp:133-160) is walked again with that test in the
+    loop.  Frames, traced rays and reference-equivalent get_hit calls are equal; exact_boxes = 2 (no second walk) is
+    allowed a few pixels; and a queue too small for the suspects makes the call fall back to the reference-arithmetic
+    mode - still the same frame."""
+    sc, kw = {"bunny_phong": lambda: (scenes.bunny(phong_surroundings=True), dict(width=480, height=270, hfov=60, spp=2, spr=3, max_bounce=2, eps=1e-3)),
+              "mirror_room": lambda: (scenes.mirror_room(12, sphere_res=12), dict(width=320, height=180, hfov=60, spp=2, spr=2, max_bounce=3, eps=1e-3)),
+              "glass_balls": lambda: (scenes.glass_balls(12), dict(width=256, height=144, hfov=54.5, spp=2, spr=3, max_bounce=3, max_refrac_bounce=5, eps=1e-3)),
+              "field": lambda: (scenes.bunny_field(60, seed=5), dict(width=320, height=180, hfov=60, spp=2, spr=2, max_bounce=2, eps=1e-3))}[name]()
+    g = api.TracerScene(sc)
+    frames, stats = {}, {}
+    for mode in (1, 0, 2):
+        opt = Options(jitter_mode=RT_JITTER_HASH, seed=9, exact_boxes=mode, **kw)
+        frames[mode], stats[mode] = g.render_rect(opt, 0, 0, opt.width, opt.height)
+    assert bits_equal(frames[0], frames[1]).all()
+    for field in ("rays_closest", "rays_any", "ref_get_hit_calls", "levels"):
+        assert getattr(stats[0], field) == getattr(stats[1], field), field
+    assert (~bits_equal(frames[2], frames[1]).all(axis=-1)).mean() <= 1e-4
+    assert list(stats[1].reserved_) == [0, 0, 0] and list(stats[2].reserved_) == [0, 0, 0] and stats[0].reserved_[0] == 0
+    redone = stats[0].reserved_[1] + stats[0].reserved_[2]
+    print(name, "rays walked twice:", stats[0].reserved_[1], "+", stats[0].reserved_[2], "of", stats[0].rays_closest, "+", stats[0].rays_any)
+    assert redone <= 1e-3 * (stats[0].rays_closest + stats[0].rays_any)
+    # a batch of rays through the same three modes
+    P = np.concatenate([m.pos.reshape(-1, 3)[::5] for m in sc.meshes])
+    c = P.mean(0)
+    org, d = random_rays(60000, 21, center=c, spread=2.5 * float(np.abs(P - c).max()))
+    rng = np.random.RandomState(2)
+    k = len(org) // 2                                           # half of them exactly at corners of triangles
+    dd = P[rng.randint(len(P), size=k)] - org[-k:]
+    d[-k:] = (dd / np.maximum(np.linalg.norm(dd, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+    t1, i1, n1 = g.trace(org, d, 1e-3, np.inf, exact_boxes=1)
+    t0, i0, n0 = g.trace(org, d, 1e-3, np.inf, exact_boxes=0)
+    assert (i0 == i1).all() and bits_equal(t0, t1).all() and bits_equal(n0, n1).all()
+    a1, _, _ = g.trace(org, d, 1e-3, 1e4, any_hit=True, exact_boxes=1)
+    a0, _, _ = g.trace(org, d, 1e-3, 1e4, any_hit=True, exact_boxes=0)
+    assert (np.isfinite(a0) == np.isfinite(a1)).all()
+    _, i2, _ = g.trace(org, d, 1e-3, np.inf, exact_boxes=2)
+    assert (i2 == i1)[:-k].mean() >= 0.9999                     # (rays through a corner: any of its triangles may win there)
+    with pytest.raises(api.RtError, match="exact_boxes"):
+        g.trace(org[:4], d[:4], 1e-3, np.inf, exact_boxes=3)
+    with pytest.raises(api.RtError, match="exact_boxes"):
+        g.render_rect(Options(jitter_mode=RT_JITTER_HASH, seed=9, exact_boxes=-1, **kw), 0, 0, 8, 8)
+    if redone:
+        # a scene handle whose redo lists take one entry: the second suspect of a launch overflows them
+        monkeypatch.setenv("RT_AMD_DEBUG_REDO_CAP", "1")
+        small = api.TracerScene(sc)
+        monkeypatch.delenv("RT_AMD_DEBUG_REDO_CAP")
+        opt = Options(jitter_mode=RT_JITTER_HASH, seed=9, exact_boxes=0, **kw)
+        f, st = small.render_rect(opt, 0, 0, opt.width, opt.height)
+        assert bits_equal(f, frames[1]).all()
+        assert st.reserved_[0] == 1 or st.reserved_[1] + st.reserved_[2] == redone
+        if name == "glass_balls":                # two suspects in one launch of this frame
+            assert st.reserved_[0] == 1
+        assert (st.rays_closest, st.rays_any) == (stats[1].rays_closest, stats[1].rays_any)
+        f2, st2 = small.render_rect(opt, 0, 0, opt.width, opt.height)          # and the handle is good for the next call
+        assert bits_equal(f2, frames[1]).all()
 
 
 def test_calls_on_one_handle_from_two_streams_do_not_race():
