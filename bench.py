@@ -125,6 +125,10 @@ def parse_args(argv):
     ap.add_argument("--scale", type=float, default=1.0,
                     help="render the workload at this fraction of its width and height (rehearsals of the heavy workloads; a "
                          "scaled run is not the benchmark and says so in config.scale)")
+    ap.add_argument("--box-mode", type=int, default=0, choices=[0, 1, 2],
+                    help="rt_options.exact_boxes of the timed frames: 0 the pruning traversal whose answers are checked against the "
+                         "reference's leaf boxes (the default, what the benchmark is), 1 the reference's arithmetic on its own tree, "
+                         "2 the pruning traversal unchecked (config.box_mode says which)")
     ap.add_argument("--verify", action="store_true",
                     help="check that the gathered frame equals the same frame rendered whole on this rank")
     return ap.parse_args(argv)
@@ -163,7 +167,7 @@ def main(argv=None):
     scene = make()
     if args.scale != 1.0:
         kw = dict(kw, width=max(8, int(kw["width"] * args.scale)), height=max(8, int(kw["height"] * args.scale)))
-    opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=0, **kw)
+    opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=args.box_mode, **kw)
     W, H = opt.width, opt.height
     # A rank's share of a millisecond frame is too small to keep its GPU busy (ramp-up and tail of small grids), so
     # consecutive frames alternate over three scene handles and streams.  Scenes whose materials spawn rays get ONE: their
@@ -279,7 +283,7 @@ def main(argv=None):
                    "sharding": ("%d-row bands interleaved over ranks, one all_gather of the %s rows per frame, overlapped with the "
                                 "next frames; consecutive frames alternate over %d streams per rank"
                                 % (BAND_ROWS, "8-bit" if u8 else "float", n_streams)) if world > 1 else "none",
-                   "streams": n_streams, "spinup_frames": spinup, "scale": args.scale,
+                   "streams": n_streams, "spinup_frames": spinup, "scale": args.scale, "box_mode": args.box_mode,
                    "verified": bool(args.verify)},
         "ms_per_frame": round(ms_per_step, 4),
     }

@@ -63,14 +63,15 @@ __device__ __forceinline__ void redo_push(uint32_t* count, T* list, uint32_t cap
     if (at < cap) list[at] = entry; else *fault = 2u;
 }
 
-template <bool EXACT, bool COUNT, bool DEEP = true>
+// CHECK (pruning traversal only): the winner is checked against its reference leaf's box and a suspect ray queued
+template <bool EXACT, bool COUNT, bool DEEP = true, bool CHECK = false>
 __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work, RedoQueue redo) {
     const int64_t i = (int64_t)xcd_block() * BLOCK + threadIdx.x;
     uint32_t kids = 0, nn = 0, nt = 0;
     RT_DECLARE_STACK_T(st, DEEP);
     bool suspect = false;
-    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr, (!EXACT && redo.cap) ? &suspect : nullptr);
-    if (!EXACT && suspect) redo_push(redo.count_extend, redo.list_extend, redo.cap, (uint32_t)i, sc.fault);
+    if (i < n) kids = (uint32_t)body_extend<EXACT>(sc, P, L, st, i, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr, (!EXACT && CHECK) ? &suspect : nullptr);
+    if (!EXACT && CHECK && suspect) redo_push(redo.count_extend, redo.list_extend, redo.cap, (uint32_t)i, sc.fault);
     if (!P.can_spawn) { add_work<COUNT>(work, nn, nt); return; }     // no material of the scene spawns rays: nothing to count
     kids = wave_sum(kids);
     // one atomic per wave on ONE word would queue up in a single L2 channel (about 8 ns each): 64 words 128 bytes apart
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_redo(DScene sc, RenderParams P
     });
 }
 
-template <bool EXACT, bool COUNT, bool DEEP = true>
+template <bool EXACT, bool COUNT, bool DEEP = true, bool CHECK = false>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Level L, int64_t n_items, FastDiv div_nodes, uint32_t n_nodes, unsigned long long* traced, unsigned long long* work, RedoQueue redo) {
     const int R = P.spr + 1, per_wave = 64 / R;
     const int lane = threadIdx.x & 63;
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene sc, RenderParams P, Lev
     if (item && shadow_item(sc, P, L, w, it)) {
         did = 1;
         bool suspect = false;
-        reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr, (!EXACT && redo.cap) ? &suspect : nullptr);
-        if (!EXACT && suspect) redo_push(redo.count_shadow, redo.list_shadow, redo.cap, ((unsigned long long)w << 4) | (unsigned long long)k, sc.fault);
+        reached = shadow_ray<EXACT>(sc, P, it, st, k, COUNT ? &nn : nullptr, COUNT ? &nt : nullptr, (!EXACT && CHECK) ? &suspect : nullptr);
+        if (!EXACT && CHECK && suspect) redo_push(redo.count_shadow, redo.list_shadow, redo.cap, ((unsigned long long)w << 4) | (unsigned long long)k, sc.fault);
     }
     const unsigned long long mask = __ballot(reached);
     if (did && k == 0) store_unocc(sc, P, L, w, (uint32_t)__popcll((mask >> lane) & ((1ull << R) - 1ull)));
@@ -308,10 +309,13 @@ void launch_extend(bool exact, const DScene& sc, const RenderParams& P, const Le
     if (redo && !exact) q = *redo;
     if (work) {
         if (exact) k_extend<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work, q);
+        else if (q.cap) k_extend<false, true, true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work, q);
         else k_extend<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, work, q);
     } else {
         if (exact) k_extend<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
+        else if (sc.shallow && q.cap) k_extend<false, false, false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
         else if (sc.shallow) k_extend<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
+        else if (q.cap) k_extend<false, false, true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
         else k_extend<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n, counters, nullptr, q);
     }
     if (q.cap) k_extend_redo<<<REDO_BLOCKS, BLOCK, 0, s>>>(sc, P, L, counters, q);
@@ -327,10 +331,13 @@ void launch_shadow(bool exact, const DScene& sc, const RenderParams& P, const Le
     if (redo && !exact) q = *redo;
     if (work) {
         if (exact) k_shadow<true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work, q);
+        else if (q.cap) k_shadow<false, true, true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work, q);
         else k_shadow<false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, work, q);
     } else {
         if (exact) k_shadow<true, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
+        else if (sc.shallow && q.cap) k_shadow<false, false, false, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
         else if (sc.shallow) k_shadow<false, false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
+        else if (q.cap) k_shadow<false, false, true, true><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
         else k_shadow<false, false><<<g, BLOCK, 0, s>>>(sc, P, L, n_items, dn, n_nodes, traced, nullptr, q);
     }
     if (q.cap) k_shadow_redo<<<REDO_BLOCKS, BLOCK, 0, s>>>(sc, P, L, q);

@@ -28,7 +28,8 @@ import bench  # noqa: E402
 def short(name):
     k = name[name.index("k_"):]
     base = k.split("<")[0].split("(")[0]
-    counting = "<" in k and k.split("<")[1].split(">")[0].replace(" ", "").endswith(",true")
+    targs = k.split("<")[1].split(">")[0].replace(" ", "").split(",") if "<" in k else []
+    counting = len(targs) > 1 and targs[1] in ("true", "1")      # k_extend / k_shadow <EXACT, COUNT, ...>
     return base, counting
 
 
