@@ -529,27 +529,29 @@ def test_headless_frame_driver(oracle_mod, tmp_path):
 @pytest.mark.parametrize("name", ["bunny_lambert_1080p", "bunny_phong_1080p", "mirror_room", "glass_balls"])
 def test_bench_workloads_both_box_modes_agree(name):
     """Every bench workload at a quarter of its size, rendered with the reference's slab arithmetic on the reference's
-    trees (the mode the oracle pins bit for bit on the small frames above) and with the pruning traversal on the
-    surface-area-heuristic trees (the mode the bench times): the frames agree in all but a few pixels per ten
-    thousand, rays are conserved, and the 8-bit images differ by at most one step."""
+    trees (the mode the oracle pins bit for bit on the small frames above), with the pruning traversal on the
+    surface-area-heuristic trees whose winners are checked against the reference's leaf boxes (the mode the bench times):
+    the same frame bit for bit and the same rays; and with the unchecked pruning traversal: all but a few pixels per
+    ten thousand, the 8-bit images within one step."""
     import bench
     make, kw = bench.WORKLOADS[name]
     kw = dict(kw, width=kw["width"] // 2, height=kw["height"] // 2)
     g = api.TracerScene(make())
-    frames, stats = [], []
-    for exact in (1, 0):
-        opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=exact, **kw)
-        f, st = g.render_rect(opt, 0, 0, opt.width, opt.height)
-        frames.append(f); stats.append(st)
-    a, b = frames
+    frames, stats = {}, {}
+    for mode in (1, 0, 2):
+        opt = Options(jitter_mode=RT_JITTER_HASH, seed=1, exact_boxes=mode, **kw)
+        frames[mode], stats[mode] = g.render_rect(opt, 0, 0, opt.width, opt.height)
+    assert bits_equal(frames[0], frames[1]).all()
+    assert (stats[0].rays_closest, stats[0].rays_any, stats[0].ref_get_hit_calls) == (stats[1].rays_closest, stats[1].rays_any, stats[1].ref_get_hit_calls)
+    a, b = frames[1], frames[2]
     assert (np.isnan(a) == np.isnan(b)).mean() >= 0.9999
     same = bits_equal(a, b).all(axis=-1)
     assert same.mean() >= 0.999
     u = np.abs(api.resolve_u8(a).astype(int) - api.resolve_u8(b).astype(int))
     assert (u > 1).mean() < 1e-3
     # which rays exist does not depend on the box mode except through those few pixels
-    assert abs(stats[0].rays_closest - stats[1].rays_closest) <= 1e-3 * stats[0].rays_closest
-    assert abs(stats[0].rays_any - stats[1].rays_any) <= 1e-3 * stats[0].rays_any
+    assert abs(stats[1].rays_closest - stats[2].rays_closest) <= 1e-3 * stats[1].rays_closest
+    assert abs(stats[1].rays_any - stats[2].rays_any) <= 1e-3 * stats[1].rays_any
 
 
 def test_ten_million_triangle_field_sample(oracle_mod):
