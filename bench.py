@@ -153,7 +153,13 @@ def main(argv=None):
     if os.environ.get("RT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
-    if world > 1:
+    # RT_BENCH_REHEARSE_GATHER=1: one rank goes through the process group, the pipelined loop and the all-gather all the
+    # same (what several ranks do, on a box with one GPU - RCCL runs a one-rank collective on its own stream)
+    rehearse = world == 1 and os.environ.get("RT_BENCH_REHEARSE_GATHER") == "1"
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1 or rehearse:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RT_BENCH_BACKEND=gloo lets several ranks rehearse the sharded path on ONE GPU (RCCL refuses that)
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -162,6 +168,12 @@ def main(argv=None):
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     api.init(-1)
+
+    def barrier():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[dev.index])       # names the device instead of leaving RCCL to guess it
+        else:
+            dist.barrier()
 
     make, kw = WORKLOADS[args.workload]
     scene = make()
@@ -174,7 +186,7 @@ def main(argv=None):
     # shares run for many milliseconds, and every handle keeps level queues of its own (up to a quarter of the free memory
     # each, held until the handle is destroyed).
     spawns = any(scene.materials[m.material].kind in (2, 3) for m in scene.meshes)
-    n_streams = args.streams if args.streams > 0 else (1 if (world == 1 or spawns) else 3)
+    n_streams = args.streams if args.streams > 0 else (1 if ((world == 1 and not rehearse) or spawns) else 3)
     tracers = [api.TracerScene(scene) for _ in range(n_streams)]      # calls on one handle serialise: a handle per stream
     tracer = tracers[0]
     stream = torch.cuda.current_stream().cuda_stream
@@ -185,7 +197,8 @@ def main(argv=None):
     if world > 1:
         opt.row_stride, opt.row_band, opt.row_phase = world, BAND_ROWS, rank
     u8 = args.gather == "u8"
-    gather = FrameGather(H, W, world, BAND_ROWS, dev, dtype=torch.uint8 if u8 else torch.float32, flipped=u8) if world > 1 else None
+    gather = FrameGather(H, W, world, BAND_ROWS, dev, dtype=torch.uint8 if u8 else torch.float32, flipped=u8,
+                         collective_on_one_rank=rehearse) if (world > 1 or rehearse) else None
     # n_sets sets of buffers: the gather of frame k overlaps the rendering of the next frames
     rgb = [torch.empty((max(n_local, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(n_sets)]
     bytes_ = [(gather.new_local() if (gather and u8) else torch.empty((max(n_local, 1), W, 3), dtype=torch.uint8, device=dev)) for _ in range(n_sets)]
@@ -241,13 +254,13 @@ def main(argv=None):
         torch.cuda.synchronize()
     run(args.warmup)
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frame = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -283,7 +296,7 @@ def main(argv=None):
                    "sharding": ("%d-row bands interleaved over ranks, one all_gather of the %s rows per frame, overlapped with the "
                                 "next frames; consecutive frames alternate over %d streams per rank"
                                 % (BAND_ROWS, "8-bit" if u8 else "float", n_streams)) if world > 1 else "none",
-                   "streams": n_streams, "spinup_frames": spinup, "scale": args.scale, "box_mode": args.box_mode,
+                   "streams": n_streams, "gather_rehearsal": bool(rehearse), "spinup_frames": spinup, "scale": args.scale, "box_mode": args.box_mode,
                    "verified": bool(args.verify)},
         "ms_per_frame": round(ms_per_step, 4),
     }
@@ -307,8 +320,8 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, opt, ms_per_step)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
+    if world > 1 or rehearse:
+        barrier()
         dist.destroy_process_group()
     return 0
 

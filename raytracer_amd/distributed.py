@@ -26,8 +26,11 @@ def local_to_image_rows(height, world_size, rank, band_rows=8):
 class FrameGather:
     """All-gather of the ranks' row shares into whole frames, reusable across frames (buffers and index are cached)."""
 
-    def __init__(self, height, width, world_size, band_rows, device, group=None, dtype=torch.float32, flipped=False):
-        """flipped: the ranks exchange their rows as rt_resolve_u8 writes them - top row first WITHIN the share (local
+    def __init__(self, height, width, world_size, band_rows, device, group=None, dtype=torch.float32, flipped=False,
+                 collective_on_one_rank=False):
+        """collective_on_one_rank: with a single rank, still go through the process group's all-gather instead of a plain
+        copy (a rehearsal of the RCCL path - its own stream, asynchronous work handles - on a box with one GPU).
+        flipped: the ranks exchange their rows as rt_resolve_u8 writes them - top row first WITHIN the share (local
         row l of a share of n rows sits at n-1-l) - and the assembled frame is top-down as well (the 8-bit image the
         reference's save_jpg builds, reference src/main.cpp:157-167)."""
         self.h, self.w, self.world, self.group, self.dtype = height, width, world_size, group, dtype
@@ -45,6 +48,7 @@ class FrameGather:
                     src[y] = r * self.max_rows + l
         self.src = src.to(device)
         self.device = device
+        self.copy_only = world_size == 1 and not collective_on_one_rank
 
     def new_local(self):
         """A buffer for this rank's rows, padded to the largest share so that all ranks gather equal sizes."""
@@ -55,7 +59,7 @@ class FrameGather:
 
     def start(self, local, stack):
         """Starts the all-gather of `local` into `stack`; returns a handle to pass to finish() (None on one rank)."""
-        if self.world == 1:
+        if self.copy_only:
             stack.copy_(local)
             return None
         if local.is_cuda and dist.get_backend(self.group) == "gloo":

@@ -140,3 +140,91 @@ def test_two_ranks_share_a_frame_of_a_scene_that_spawns_rays(workload, streams):
     assert line["n_gpus"] == 2 and line["config"]["verified"] is True and line["config"]["scale"] == 0.34
     assert line["config"]["streams"] == (streams or 1)
     assert line["config"]["rays_per_frame"] > 50_000_000
+
+
+_RCCL_REHEARSAL = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+from raytracer_amd import api, scenes
+from raytracer_amd._abi import Options, RT_JITTER_HASH
+from raytracer_amd.distributed import FrameGather, run_pipelined
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[1]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev = torch.device("cuda", 0)
+api.init(-1)
+W, H, BAND = 640, 356, 8
+opt = Options(width=W, height=H, hfov=60, spp=2, spr=3, max_bounce=3, jitter_mode=RT_JITTER_HASH, seed=1)
+tracers = [api.TracerScene(scenes.bunny()) for _ in range(3)]
+want = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+tracers[0].render_rect(opt, 0, 0, W, H, out=want, stats=False)
+want8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+api.resolve_u8(want, out=want8)
+torch.cuda.synchronize()
+for n_streams in (1, 3):
+    fg = FrameGather(H, W, 1, BAND, dev, dtype=torch.uint8, flipped=True, collective_on_one_rank=True)
+    n_sets = max(2, n_streams)
+    rgb = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    locals_ = [fg.new_local() for _ in range(n_sets)]
+    stacks = [fg.new_stack() for _ in range(n_sets)]
+    streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else None
+
+    def render(k, buf):
+        b = k % n_sets
+        cur = torch.cuda.current_stream().cuda_stream
+        o = Options.from_buffer_copy(opt)
+        o.seed = 1 if k == 8 else 100 + k                 # only the last frame is the one compared
+        tracers[b % n_streams].render_rect(o, 0, 0, W, H, out=rgb[b], stats=False, stream=cur)
+        api.resolve_u8(rgb[b], out=buf, stream=cur)
+    frame = run_pipelined(9, render, fg, locals_, stacks, streams)
+    torch.cuda.synchronize()
+    assert frame.shape == (H, W, 3) and bool((frame == want8).all()), "gathered frame differs with %d streams" % n_streams
+dist.barrier()
+dist.destroy_process_group()
+print("rccl rehearsal ok")
+"""
+
+
+@pytest.mark.gpu
+def test_one_rank_rehearses_the_rccl_gather():
+    """The exchange of the sharded path on the backend the benchmark uses with several GPUs (RCCL: collectives on a stream
+    of the process group's own, asynchronous work handles), as far as one GPU allows: a single rank whose FrameGather goes
+    through all_gather_into_tensor instead of the one-rank copy, nine pipelined frames with different seeds on one and on
+    three streams, the last one compared with the frame rendered directly."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-c", _RCCL_REHEARSAL, str(port)], cwd=ROOT, capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0 and "rccl rehearsal ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_rehearses_its_gather_on_rccl_with_one_rank():
+    """bench.py with RT_BENCH_REHEARSE_GATHER=1: one rank initialises the RCCL process group and runs the code the
+    multi-GPU job runs - three handles on three streams, the pipelined loop, one all_gather_into_tensor per frame, the
+    row reordering - and checks the gathered frame against the frame rendered whole."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RT_BENCH_REHEARSE_GATHER="1", MASTER_PORT=str(port), RT_BENCH_WATCHDOG="150")
+    for gather in ("u8", "f32"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--verify", "--steps", "6", "--warmup", "2", "--gather", gather,
+                            "--no-cpu-baseline", "--no-workloads", "--no-roofline"], env=env, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["config"]["gather_rehearsal"] is True and line["config"]["verified"] is True and line["config"]["streams"] == 3
