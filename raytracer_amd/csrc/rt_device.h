@@ -66,9 +66,16 @@ __device__ __forceinline__ int32_t packed_ref(float a, float b, float c, float d
     return (int32_t)__builtin_amdgcn_perm(cd, ab, 0x05040100u);
 }
 
-#ifndef RT_ANY_HIT_NEAR_FIRST
-#define RT_ANY_HIT_NEAR_FIRST 0   // 1: any-hit rays also visit the nearer child first (measured: no faster, and three
-                                  // more half-rate instructions per node)
+#ifndef RT_ANY_HIT_ORDER
+// Order in which an any-hit ray descends where it hits both children.  Only a ray that IS occluded can gain from an order
+// (a free ray walks every box it meets, whatever the order), and it gains when it reaches a triangle in its way sooner.
+// Light rays start on a surface, inside the boxes of that surface's own neighbourhood, whose triangles lie beside or
+// behind them; what blocks them stands farther along the ray.  4, the child whose box the ray LEAVES later, is what
+// sends them there: frames 7 % (bunny), 17 % (Phong bunny), 15 % (mirror room), 13 % (glass balls) faster than 0, left
+// child first, with the same answers.  1 (the child entered first, the order of nearest-hit rays) is slower than no order at
+// all, 2 (entered later) and 3 (longest stay) lie between; a leaf before an inner node, ties of 4 broken by entry, and the
+// mean of entry and exit were tried on top of 4 and change nothing.
+#define RT_ANY_HIT_ORDER 4
 #endif
 
 namespace rt {
@@ -258,7 +265,7 @@ RT_HD bool slab_exact(const float* b, V3 o, V3 d, float& tmin) {
 struct SlabRay { V3 rd, en, ef; };
 
 template <int OCT>
-RT_HD bool slab_fast(const float* b, V3 o, const SlabRay& r, float lo, float lim, float& tmin) {
+RT_HD bool slab_fast(const float* b, V3 o, const SlabRay& r, float lo, float lim, float& tmin, float& tfar) {
     float tn, tf;
     if (OCT < 8) {
         // One fused multiply-add per plane, bound / d - e / d, instead of a subtraction and a multiplication.  The
@@ -279,7 +286,8 @@ RT_HD bool slab_fast(const float* b, V3 o, const SlabRay& r, float lo, float lim
         tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
     }
     tmin = fmaxf(tn, lo);
-    return !(tmin > fminf(tf * 1.000001f, lim));
+    tfar = fminf(tf * 1.000001f, lim);
+    return !(tmin > tfar);
 }
 
 // 1/d (hardware reciprocal: within one unit in the last place, well inside what slab_fast allows for) and the widened
@@ -433,7 +441,7 @@ RT_HD bool tri_test(const float4 p0, const float4 p1, const float4 p2, V3 o, V3 
 // One inner node: tests both children and returns the next reference to visit (the far child is pushed when both are
 // hit; RT_NONE when the stack is empty).  The sixteen node words are passed as scalars so that the same code serves
 // words held in vector registers and words held in scalar registers (a node the whole wave fetched once).
-template <bool EXACT, int OCT, bool ORDER, class ST>
+template <bool EXACT, int OCT, int ORDER, class ST>
 RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8,
                         float b9, float b10, float b11, int32_t r0, int32_t r1, int32_t r2, int32_t r3, ST& st,
                         V3 o, V3 d, const SlabRay& rd, float lo, float lim) {
@@ -441,13 +449,14 @@ RT_HD int32_t node_step(float b0, float b1, float b2, float b3, float b4, float 
     const float rb[6] = {b6, b7, b8, b9, b10, b11};
     // the reference's own leaves when its exact box tests are asked for, the refined ones otherwise
     const int32_t lref = EXACT ? r0 : r2, rref = EXACT ? r1 : r3;
-    float tl, tr;
+    float tl, tr, fl = 0.f, fr = 0.f;
     bool hl, hr;
     if (EXACT) { hl = slab_exact(lb, o, d, tl); hr = slab_exact(rb, o, d, tr); }
-    else { hl = slab_fast<OCT>(lb, o, rd, lo, lim, tl); hr = slab_fast<OCT>(rb, o, rd, lo, lim, tr); }
+    else { hl = slab_fast<OCT>(lb, o, rd, lo, lim, tl, fl); hr = slab_fast<OCT>(rb, o, rd, lo, lim, tr, fr); }
     hr = hr && (rref != RT_NONE);
     if (hl && hr) {
-        const bool swap = !EXACT && ORDER && tr < tl;
+        // ORDER 1: the child entered first; 2: the child entered last; 3: the child the ray stays in longest; 4: the child left last
+        const bool swap = !EXACT && ((ORDER == 1 && tr < tl) || (ORDER == 2 && tr > tl) || (ORDER == 3 && (fr - tr) > (fl - tl)) || (ORDER == 4 && fr > fl));
         st.push(swap ? lref : rref);
         return swap ? rref : lref;
     }
@@ -480,7 +489,7 @@ RT_HD bool traverse_oct(const DScene& sc, ST& st, V3 o, V3 d, const SlabRay& rd,
         while (cur >= 0) {
             if (n_nodes) RT_COUNT_STEP(*n_nodes);
             const float lim = EXACT ? INFINITY : (ANY ? t1 : prune_limit(best.t));
-            RT_NODE_STEP(EXACT, OCT, (!ANY || RT_ANY_HIT_NEAR_FIRST), sc.nodes, cur, st, o, d, rd, lo, lim);
+            RT_NODE_STEP(EXACT, OCT, (ANY ? RT_ANY_HIT_ORDER : 1), sc.nodes, cur, st, o, d, rd, lo, lim);
         }
         if (cur == RT_NONE) break;
         // ---- one leaf: a run of consecutive triangles
