@@ -43,7 +43,7 @@ struct Built { int32_t ref, ref_fine; Box box; int depth; };
 
 constexpr int RT_FINE_LEAF = 4;
 #ifndef RT_SAH_LEAF
-#define RT_SAH_LEAF 4       // most triangles in a leaf of the surface-area-heuristic tree
+#define RT_SAH_LEAF 3       // most triangles in a leaf of the surface-area-heuristic tree (2, 3, 4, 6, 8 measured: 3 is 1 - 4 % ahead of 4)
 #endif
 
 inline void set_node(Node64& n, const Built& L, const Built& R) {

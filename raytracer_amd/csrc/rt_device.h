@@ -310,10 +310,17 @@ RT_HD SlabRay make_slab_ray(V3 o, V3 d, bool& usable_oct) {
 // lim, "this subtree starts beyond the best hit so far": the triangle distances it is compared with are rounded
 // results of a different formula than the box distances, so equal or almost equal hits in different leaves (a ray
 // through a shared vertex or edge) must all be looked at: the reference picks among them by (t, tie rank), which
-// needs every candidate.  lo, "this box ends before the ray's interval starts": a ray that leaves a flat surface
-// skips that surface's own boxes at once instead of descending to the leaves around its origin.
-RT_HD float prune_limit(float best_t) { return best_t * 1.00001f; }
-RT_HD float entry_limit(float t0) { return fmaxf(t0 * 0.99999f, 0.f); }
+// needs every candidate.  The Cramer distance of a sliver met at a shallow angle is good to a few 1e-5 of itself, not to
+// the 1e-7 of a box distance (a ray aimed at a vertex of the dome's rim from 16 units away: 15.95199 and 15.95211 from
+// the two slivers that share the vertex, 15.95229 to the vertex itself), so the slack is a thousandth: with 1e-5 the
+// nearer of those two was pruned whenever the farther was met first.  Costs nothing measurable (subtrees that begin
+// within 0.1 % beyond the best hit are few).  lo, "this box ends before the ray's interval starts": a ray that leaves a
+// flat surface skips that surface's own boxes at once instead of descending to the leaves around its origin.
+#ifndef RT_PRUNE_SLACK
+#define RT_PRUNE_SLACK 1.001f
+#endif
+RT_HD float prune_limit(float best_t) { return best_t * RT_PRUNE_SLACK; }
+RT_HD float entry_limit(float t0) { return fmaxf(t0 * 0.999f, 0.f); }
 
 // Work counters of the counting kernels: steps of this lane, or (profiling build, -DRT_COUNT_WAVE_STEPS) steps of the
 // wave - only the first active lane counts, so the sum over lanes * 64 against the per-lane sum is the lane
