@@ -136,6 +136,7 @@ void free_level(LevelBuf& b) {
     if (b.L.dir) (void)hipFree(b.L.dir);
     if (b.L.meta) (void)hipFree(b.L.meta);
     if (b.L.rec) (void)hipFree(b.L.rec);
+    if (b.L.geo) (void)hipFree(b.L.geo);
     if (b.L.hit) (void)hipFree(b.L.hit);
     if (b.L.pos) (void)hipFree(b.L.pos);
     if (b.L.tri) (void)hipFree(b.L.tri);
@@ -168,6 +169,7 @@ int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit, bool draws) 
         HIP_TRY(hipMalloc((void**)&b.L.unocc, cap * lights * sizeof(uint8_t)));
     } else {
         HIP_TRY(hipMalloc((void**)&b.L.rec, cap * sizeof(rt::NodeRec)));
+        HIP_TRY(hipMalloc((void**)&b.L.geo, cap * sizeof(rt::NodeGeo)));
     }
     if (draws) {
         HIP_TRY(hipMalloc((void**)&b.L.draw, cap * sizeof(rt::DrawRec)));

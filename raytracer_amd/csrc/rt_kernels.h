@@ -22,12 +22,17 @@ enum { RAY_SHADOW = 0, RAY_REFLECT = 1, RAY_REFRACTIVE = 2,      // src/ray.h:10
        RAY_NONE = 3 };                                          // padding slot of a partly covered pixel tile
 enum { RT_MAX_LEVELS = 20 };
 
-// Everything the kernels after the nearest-hit search need to know about a node, in ONE 64-byte record: the replay
+// Everything the kernels after the nearest-hit search need to know about a node, in TWO 32-byte records: the replay
 // walks a pixel's ray tree node by node, and neighbouring lanes are at unrelated nodes below the first level, so every
-// separately stored field costs a memory sector of its own.
-struct alignas(64) NodeRec {
+// separately stored field costs a memory sector of its own.  NodeRec is what every node of the walk needs (which
+// children, what kind of ray, its weight, what it hit, the light counts); NodeGeo - where it hit - only the nodes that are
+// shaded or spawn: a ray that hit nothing, or a mirror at the last bounce, draws its parent's colour and never reads it
+// (most nodes of a room of mirrors: the memory system fetches 32-byte sectors, so the replay moves a third fewer bytes).
+struct alignas(32) NodeGeo {
     float px, py, pz; uint32_t key;   // hit point e + t d (src/ray.cpp:32-35); path key of the node's ray
     float nx, ny, nz, t;              // unit normal at the hit; t
+};
+struct alignas(32) NodeRec {
     int32_t kid_base;                 // first child in the next level (written by spawn)
     int32_t flags;                    // type | depth << 8 | rank << 16 | REC_SAME_MEDIUM; byte 3 = number of children
     float weight;                     // src/ray.h:36
@@ -49,6 +54,7 @@ struct Level {
     int4* meta;        // x parent index in the previous level (-1 at level 0), y = type | depth<<8 | rank<<16,
                        // z = bits(refraci), w = index (this level) of the node whose ray the companion shadow ray repeats
     NodeRec* rec;      // results of a stored level
+    NodeGeo* geo;
     // results of the implicit level 0, one array per field: there neighbouring lanes ARE neighbouring nodes, so
     // separate arrays are read and written fully coalesced and fields a scene never uses cost nothing
     float4* hit;       // xyz unit normal at the hit, w = t
@@ -69,8 +75,8 @@ struct Level {
 RT_HD int32_t res_tri(const Level& L, int64_t i) { return L.implicit ? L.tri[i] : L.rec[i].tri; }
 // material index of the hit; v = res_tri(L, i) >= 0
 RT_HD int32_t res_material(const DScene& sc, const Level& L, int32_t v) { return L.implicit ? sc.mesh_mat[sc.info[v].mesh] : v; }
-RT_HD float4 res_pos(const Level& L, int64_t i) { return L.implicit ? L.pos[i] : *reinterpret_cast<const float4*>(&L.rec[i].px); }
-RT_HD float4 res_hit(const Level& L, int64_t i) { return L.implicit ? L.hit[i] : *reinterpret_cast<const float4*>(&L.rec[i].nx); }
+RT_HD float4 res_pos(const Level& L, int64_t i) { return L.implicit ? L.pos[i] : *reinterpret_cast<const float4*>(&L.geo[i].px); }
+RT_HD float4 res_hit(const Level& L, int64_t i) { return L.implicit ? L.hit[i] : *reinterpret_cast<const float4*>(&L.geo[i].nx); }
 // children the nearest-hit search announced for node i
 RT_HD int res_kid_count(const Level& L, int64_t i) { return L.implicit ? L.kids[i].y : (int)((uint32_t)L.rec[i].flags >> 24); }
 RT_HD void set_kids(const Level& L, int64_t i, int32_t base, int cnt) {
@@ -234,8 +240,9 @@ RT_HD int body_extend(const DScene& sc, const RenderParams& P, const Level& L, S
     } else {
         NodeRec* R = L.rec + i;
         if (hit) {
-            *reinterpret_cast<float4*>(&R->px) = pk;
-            *reinterpret_cast<float4*>(&R->nx) = hn;
+            NodeGeo* G = L.geo + i;
+            *reinterpret_cast<float4*>(&G->px) = pk;
+            *reinterpret_cast<float4*>(&G->nx) = hn;
         }
         *reinterpret_cast<int4*>(&R->kid_base) = mk_i4(-1, flags | (kids << 24), RT_F2I(in.weight), mat);
         *reinterpret_cast<int4*>(&R->aux) = mk_i4(RT_F2I(r_theta), in.comp, 0, 0);
@@ -489,19 +496,23 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
         V3 c = v3(0, 0, 0);
         if (tri >= 0) {
             const Material M = load_material(sc.mats + res_material(sc, L, tri));
-            const float4 hn = res_hit(L, i);
-            const V3 n = f4v(hn);
-            V3 p; uint32_t key;
-            if (L.implicit) {
-                // this kernel waits for memory: recomputing the primary ray is cheaper than reading the hit point
-                const NodeIn in = primary_node(sc, P, i);
-                p = point_at(in.o, in.d, hn.w); key = in.key;
-            } else {
-                const float4 pk = res_pos(L, i);
-                p = f4v(pk); key = (uint32_t)RT_F2I(pk.w);
-            }
+            // where the ray hit: fetched only by the branches that shade (a mirror at its last bounce does not)
+            float4 hn; V3 n, p; uint32_t key;
+            auto fetch_geometry = [&]() {
+                hn = res_hit(L, i);
+                n = f4v(hn);
+                if (L.implicit) {
+                    // this kernel waits for memory: recomputing the primary ray is cheaper than reading the hit point
+                    const NodeIn in = primary_node(sc, P, i);
+                    p = point_at(in.o, in.d, hn.w); key = in.key;
+                } else {
+                    const float4 pk = res_pos(L, i);
+                    p = f4v(pk); key = (uint32_t)RT_F2I(pk.w);
+                }
+            };
             const bool use_refl = (M.kind == 2 || M.kind == 3), use_refr = (M.kind == 3);
             if (!use_refl) {                                                 // :187-200
+                fetch_geometry();
                 V3 add = apply_shade(sc, P, M, p, n, shadow_rec, key);
                 if (contrib != 1) add = vscale(add, 1 - tpc);
                 cc = vadd(cc, add);
@@ -510,6 +521,7 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
                 float prev = M.reflectivity;
                 contrib = 1 - prev;
                 for (int q = depth; q < P.D; ++q) { contrib = prev * (1 - M.reflectivity); prev = prev - contrib; }
+                fetch_geometry();
                 V3 self = apply_shade(sc, P, M, p, n, shadow_rec, key);
                 self = vscale(self, contrib);
                 if (depth == P.D) cc = self; else cc = vadd(cc, self);
@@ -524,9 +536,10 @@ RT_HD void replay_sample(const DScene& sc, const RenderParams& P, const Level* l
             } else {                                                         // :300-397
                 V3 c_add;
                 if (L.implicit ? (1.f == M.refractivity) : ((head.y & REC_SAME_MEDIUM) != 0)) {
-                    c_add.x = M.transp[0] * expf(-M.transp[0] * hn.w);
-                    c_add.y = M.transp[1] * expf(-M.transp[1] * hn.w);
-                    c_add.z = M.transp[2] * expf(-M.transp[2] * hn.w);
+                    const float t_hit = res_hit(L, i).w;
+                    c_add.x = M.transp[0] * expf(-M.transp[0] * t_hit);
+                    c_add.y = M.transp[1] * expf(-M.transp[1] * t_hit);
+                    c_add.z = M.transp[2] * expf(-M.transp[2] * t_hit);
                 } else c_add = v3(1, 1, 1);
                 RFrame F;
                 F.base = head.x; F.count = n_kids; F.next = n_kids - 1; F.refr = 1; F.r_theta = L.implicit ? L.aux[i] : aux;
