@@ -511,8 +511,7 @@ bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& 
     const std::vector<SahRef> all = b.refs;
     // candidate 1: one tree over all triangles (not tried for scenes of very many meshes: instanced fields, where the
     // per-mesh trees are the natural clusters and the build time matters)
-    const bool force_one = getenv("RT_AMD_DEBUG_ONE_TREE") != nullptr;      // measuring aid: candidate 1 whatever the costs say
-    const bool try_one = n_nonempty < 2 || n_nonempty <= 64 || force_one;
+    const bool try_one = n_nonempty < 2 || n_nonempty <= 64;
     if (try_one) {
         out->nodes.reserve((size_t)total); out->tris.reserve((size_t)total); out->info.reserve((size_t)total); out->nrm.reserve((size_t)total * 9);
         const Built root = b.build(0, (int)total, 0);      // the root is the first node emitted: index 0
@@ -584,7 +583,7 @@ bool build_sah_scene(const rt_mesh_desc* meshes, int n_meshes, const FlatScene& 
     two.max_depth = top.depth;
     const double c_one = try_one ? tree_cost(*out) : 0.0, c_two = tree_cost(two);
     if (getenv("RT_AMD_DEBUG_TREE")) fprintf(stderr, "rt_amd: expected cost, one tree %.4g, tree per mesh %.4g\n", c_one, c_two);
-    if (!force_one && (!try_one || c_two < c_one)) *out = std::move(two);
+    if (!try_one || c_two < c_one) *out = std::move(two);
     return true;
 }
 
