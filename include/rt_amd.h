@@ -117,7 +117,7 @@ typedef struct rt_options {
                                    reference's own, not merely one that is as near.
                                    1: the reference's slab arithmetic (IEEE divisions) on the reference's tree without pruning -
                                    visits exactly the triangles the reference visits; several times slower.
-                                   2: the pruning traversal without that check (2 - 4 % faster; a few pixels per million can
+                                   2: the pruning traversal without that check (1 - 6 % faster; a few pixels per million can
                                    then show a hit the reference loses between two of its boxes) */
     int32_t count_traversal;    /* 1: also count inner nodes fetched and triangles tested per kernel kind into
                                    rt_stats (slower kernels; for traffic accounting, not for timing) */
