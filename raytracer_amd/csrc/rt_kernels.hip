@@ -63,9 +63,14 @@ __device__ __forceinline__ void redo_push(uint32_t* count, T* list, uint32_t cap
     if (at < cap) list[at] = entry; else *fault = 2u;
 }
 
+// The nearest-hit kernels of the pruning traversal need 65 - 67 vector registers when left to themselves, one or three too
+// many for eight waves per SIMD; told to fit, the compiler fits them into 64 without scratch, and the eighth wave hides
+// that much more latency: mirror room nearest-hit kernel 23.2 -> 20.8 ms per frame, 10 M field 267 -> 231.  (The
+// reference-arithmetic instantiations need 94 and stay as they are.)
+#define RT_EXTEND_WAVES __attribute__((amdgpu_waves_per_eu(EXACT ? 1 : 8, 8)))
 // CHECK (pruning traversal only): the winner is checked against its reference leaf's box and a suspect ray queued
 template <bool EXACT, bool COUNT, bool DEEP = true, bool CHECK = false>
-__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work, RedoQueue redo) {
+__global__ __launch_bounds__(BLOCK) RT_EXTEND_WAVES void k_extend(DScene sc, RenderParams P, Level L, int64_t n, uint32_t* counters, unsigned long long* work, RedoQueue redo) {
     const int64_t i = (int64_t)xcd_block() * BLOCK + threadIdx.x;
     uint32_t kids = 0, nn = 0, nt = 0;
     RT_DECLARE_STACK_T(st, DEEP);
