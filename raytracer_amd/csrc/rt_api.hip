@@ -132,7 +132,6 @@ int upload(rt_scene* sc, const T* src, size_t n, const T** dst) {
 }
 
 void free_level(LevelBuf& b) {
-    if (b.L.org) (void)hipFree(b.L.org);
     if (b.L.dir) (void)hipFree(b.L.dir);
     if (b.L.meta) (void)hipFree(b.L.meta);
     if (b.L.rec) (void)hipFree(b.L.rec);
@@ -156,7 +155,6 @@ int ensure_level(LevelBuf& b, int64_t n, int lights, bool implicit, bool draws) 
     free_level(b);
     b.L.implicit = implicit ? 1 : 0;
     if (!implicit) {
-        HIP_TRY(hipMalloc((void**)&b.L.org, cap * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&b.L.dir, cap * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&b.L.meta, cap * sizeof(int4)));
     }
@@ -255,6 +253,7 @@ int rt_scene_create_ex(const rt_mesh_desc* meshes, int n_meshes, const rt_materi
                        const rt_light_desc* lights, int n_lights, const rt_camera_desc* camera, uint32_t flags, rt_scene** out) {
     if (!meshes || n_meshes <= 0 || !materials || n_materials <= 0 || !camera || !out || n_lights < 0 || (n_lights > 0 && !lights))
         return fail(RT_ERR_INVALID, "rt_scene_create: null or empty argument");
+    if (n_materials >= (1 << 22) - 1) return fail(RT_ERR_UNSUPPORTED, "more than 4194302 materials (a stored ray keeps the material it travels in in 22 bits)");
     RT_API_BEGIN
     if (n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_UNSUPPORTED, "more lights than RT_MAX_LIGHTS");
     for (int i = 0; i < n_meshes; ++i) {
@@ -856,6 +855,9 @@ static int render_impl(rt_scene* sc, const rt_options* o, int x0, int y0, int x1
                 if (rows > 4) { (void)hipGetLastError(); too_big = true; break; }    // out of memory: a lower band needs less
                 return rc;
             }
+            // the new level's rays start at the hit points of this one
+            sc->lv[lvl].L.ppos = L.implicit ? L.pos : reinterpret_cast<const float4*>(L.geo);
+            sc->lv[lvl].L.pstride = L.implicit ? 1 : 2;
             rt::launch_spawn(D, P, L, sc->lv[lvl].L, n, d_counters + 1, s);
             n = kids;
         }

@@ -49,10 +49,15 @@ enum { REC_SAME_MEDIUM = 1 << 21 };   // the ray travels in the hit material's o
 struct alignas(32) DrawRec { float cx, cy, cz, w; int32_t next_lvl, next_idx, pad0, pad1; };
 
 struct Level {
-    float4* org;       // xyz ray origin, w = bits(path key)
+    // A stored node's ray in 32 bytes.  Its origin is not stored: it is the hit point of its parent, which the parent's
+    // own results hold (ppos), and a node's children sit next to each other, so the lanes of a wave fetch few of them.
     float4* dir;       // xyz ray direction, w = weight (src/ray.h:36)
-    int4* meta;        // x parent index in the previous level (-1 at level 0), y = type | depth<<8 | rank<<16,
-                       // z = bits(refraci), w = index (this level) of the node whose ray the companion shadow ray repeats
+    int4* meta;        // x parent index in the previous level, y = type | depth << 2 | rank << 6 | medium << 10 (medium: 0 =
+                       // the ray travels where the refractive index is 1, m + 1 = inside material m: refraci of
+                       // src/render_thread.cpp:328,337 is always one of these), z = path key of the ray,
+                       // w = index (this level) of the node whose ray the companion shadow ray repeats
+    const float4* ppos;   // results of the previous level: xyz hit point of node k at ppos[k * pstride]
+    int32_t pstride;      // 1: the previous level is the implicit one (its pos array), 2: a stored one (its NodeGeo array)
     NodeRec* rec;      // results of a stored level
     NodeGeo* geo;
     // results of the implicit level 0, one array per field: there neighbouring lanes ARE neighbouring nodes, so
@@ -88,6 +93,7 @@ RT_HD void set_kids(const Level& L, int64_t i, int32_t base, int cnt) {
 struct NodeIn {
     V3 o, d; uint32_t key; float weight;
     int32_t packed;      // type | depth << 8 | rank << 16
+    int32_t medium;      // what Level::meta keeps of refraci: 0, or material + 1
     int32_t refraci;     // float bits
     int32_t comp;        // node whose ray the companion shadow ray repeats
 };
@@ -95,6 +101,7 @@ struct NodeIn {
 RT_HD int meta_type(int y) { return y & 0xff; }
 RT_HD int meta_depth(int y) { return (y >> 8) & 0xff; }
 RT_HD int meta_pack(int type, int depth, int rank) { return type | (depth << 8) | (rank << 16); }
+RT_HD int meta_store(int type, int depth, int rank, int medium) { return type | (depth << 2) | (rank << 6) | (int)((uint32_t)medium << 10); }   // Level::meta.y
 
 RT_HD V3 f4v(float4 a) { return v3(a.x, a.y, a.z); }
 RT_HD float4 mk4(V3 a, float w) { float4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = w; return r; }
@@ -120,7 +127,7 @@ RT_HD NodeIn primary_node(const DScene& sc, const RenderParams& P, int64_t g) {
     const int px = (int)tile_x * 4 + ((q & 1) | ((q >> 1) & 2)), py = (int)tile_y * 4 + (((q >> 1) & 1) | ((q >> 2) & 2));
     NodeIn n;
     n.o = v3p(sc.cam.pos); n.d = v3(0, 0, 0); n.key = 0; n.weight = 1.f;
-    n.refraci = RT_F2I(1.f); n.comp = (int32_t)g;
+    n.refraci = RT_F2I(1.f); n.medium = 0; n.comp = (int32_t)g;
     if (px >= P.rw || py >= P.band_rows) {                         // padding of a partly covered tile: never traced
         n.packed = meta_pack(RAY_NONE, 0, 0);
         return n;
@@ -134,11 +141,15 @@ RT_HD NodeIn primary_node(const DScene& sc, const RenderParams& P, int64_t g) {
 
 RT_HD NodeIn node_in(const DScene& sc, const RenderParams& P, const Level& L, int64_t i) {
     if (L.implicit) return primary_node(sc, P, i);
-    const float4 o = L.org[i], d = L.dir[i];
+    const float4 d = L.dir[i];
     const int4 m = L.meta[i];
+    const float4 o = L.ppos[(int64_t)m.x * L.pstride];
     NodeIn n;
-    n.o = f4v(o); n.d = f4v(d); n.key = (uint32_t)RT_F2I(o.w); n.weight = d.w;
-    n.packed = m.y; n.refraci = m.z; n.comp = m.w;
+    n.o = f4v(o); n.d = f4v(d); n.key = (uint32_t)m.z; n.weight = d.w;
+    n.packed = meta_pack(m.y & 3, (m.y >> 2) & 15, (m.y >> 6) & 15);
+    n.medium = (int32_t)((uint32_t)m.y >> 10);
+    n.refraci = n.medium ? RT_F2I(sc.mats[n.medium - 1].refractivity) : RT_F2I(1.f);
+    n.comp = m.w;
     return n;
 }
 
@@ -266,7 +277,7 @@ RT_HD bool shadow_item(const DScene& sc, const RenderParams& P, const Level& L, 
     if (P.skip_unlit && L.unocc[w] == (uint8_t)RT_UNLIT) { it.idle = true; return false; }   // level 0 only: such scenes have no other
     const float4 pk = res_pos(L, comp);
     it.p = f4v(pk);
-    it.key = L.implicit ? (uint32_t)RT_F2I(pk.w) : (uint32_t)RT_F2I(L.org[i].w);
+    it.key = L.implicit ? (uint32_t)RT_F2I(pk.w) : (uint32_t)L.meta[i].z;
     it.exact = vnorm(light_dir(sc.lights[it.li], it.p, P, it.key, SITE_SH_LIGHT, (uint32_t)it.li));   // Ray ctor normalises
     return true;
 }
@@ -312,30 +323,27 @@ RT_HD void spawn_child(const DScene& sc, const RenderParams& P, const Level& L, 
     const Material& M = sc.mats[res_material(sc, L, tri)];
     const V3 d = in.d;
     const V3 n = f4v(res_hit(L, i));
-    const V3 p = f4v(res_pos(L, i));
     const float pp = 2.f * vdot(d, n);                                  // mirror direction, src/linmath.h:59-65
     const V3 rd = v3(d.x - pp * n.x, d.y - pp * n.y, d.z - pp * n.z);
     const uint32_t ck = node_child(in.key, (uint32_t)k);
     if (M.kind == 2) {                                                  // src/render_thread.cpp:239-280
         const V3 dk = (k < P.spr) ? split_dir(rd, P.ray_eps, P, in.key, SITE_REFLECT_SPLIT, 0, (uint32_t)k) : rd;
-        N.org[at] = mk4(p, RT_I2F((int)ck));
         N.dir[at] = mk4(dk, in.weight);
-        int4 cm; cm.x = (int)i; cm.y = meta_pack(RAY_REFLECT, depth - 1, k); cm.z = in.refraci; cm.w = (int)(first + P.spr);
+        int4 cm; cm.x = (int)i; cm.y = meta_store(RAY_REFLECT, depth - 1, k, in.medium); cm.z = (int)ck; cm.w = (int)(first + P.spr);
         N.meta[at] = cm;
     } else {                                                            // src/render_thread.cpp:318-394
         const float refraci = RT_I2F(in.refraci);
         V3 td = v3(0, 0, 0);
         const float r_theta = refract_dir(d, n, refraci, M.refractivity, td);
         const bool both = !(r_theta <= 0);
-        const int zi = RT_F2I(M.refractivity);
-        int4 cm; cm.x = (int)i; cm.z = zi; cm.w = (int)at;
-        N.org[at] = mk4(p, RT_I2F((int)ck));
+        const int medium = res_material(sc, L, tri) + 1;                  // the children travel in the hit material (:328, :337)
+        int4 cm; cm.x = (int)i; cm.z = (int)ck; cm.w = (int)at;
         if (k == 0) {
             N.dir[at] = mk4(rd, both ? r_theta * in.weight : in.weight);
-            cm.y = meta_pack(RAY_REFRACTIVE, (refraci == 1) ? P.D : depth - 1, 0);
+            cm.y = meta_store(RAY_REFRACTIVE, (refraci == 1) ? P.D : depth - 1, 0, medium);
         } else {
             N.dir[at] = mk4(td, (1 - r_theta) * in.weight);
-            cm.y = meta_pack(RAY_REFRACTIVE, (refraci == 1) ? P.Dr : depth - 1, 1);
+            cm.y = meta_store(RAY_REFRACTIVE, (refraci == 1) ? P.Dr : depth - 1, 1, medium);
         }
         N.meta[at] = cm;
     }
